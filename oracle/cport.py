@@ -1,0 +1,95 @@
+"""ctypes wrapper for oracle/libsurfdisp_oracle.so (the C restatement).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libsurfdisp_oracle.so")
+_lib = None
+
+OK, PARTIAL, NOROOT, NEVILL, EINVAL = 0, 1, 2, 3, -1
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "surfdisp_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libsurfdisp_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        fp = ctypes.POINTER(ctypes.c_float)
+        ip = ctypes.POINTER(ctypes.c_int)
+        L.surfdisp_oracle_forward.restype = ctypes.c_int
+        L.surfdisp_oracle_forward.argtypes = [ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, fp,
+                                              ctypes.c_int, fp, fp, ip,
+                                              ctypes.POINTER(ctypes.c_long)]
+        L.surfdisp_oracle_forward_batch.restype = ctypes.c_int
+        L.surfdisp_oracle_forward_batch.argtypes = [ctypes.c_int, ctypes.c_int, ip, fp, ctypes.c_int,
+                                                    fp, ctypes.c_int, fp, fp, ip, ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).astype(np.float32))
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def forward(vp, vs, rho, h, qsinv, periods, kind):
+    """One solve -> dict(c, u, status, nsolved, n_delta)."""
+    vp, vs, rho, h, qsinv, per = map(_f32, (vp, vs, rho, h, qsinv, periods))
+    P = per.size
+    c = np.zeros(P, np.float32); u = np.zeros(P, np.float32)
+    ns = ctypes.c_int(0); nd = ctypes.c_long(0)
+    st = lib().surfdisp_oracle_forward(vp.size, int(kind), _fp(vp), _fp(vs), _fp(rho), _fp(h),
+                                       _fp(qsinv), _fp(per), P, _fp(c), _fp(u),
+                                       ctypes.byref(ns), ctypes.byref(nd))
+    return dict(c=c, u=u, status=st, nsolved=ns.value, n_delta=nd.value)
+
+
+def fast_surf(nlay, ilvry, vp, vs, rho, h, qsinv, per, nper):
+    """f2py-shaped call (fast_surf.pyf:6-19) on the C oracle."""
+    r = forward(np.asarray(vp)[:nlay], np.asarray(vs)[:nlay], np.asarray(rho)[:nlay],
+                np.asarray(h)[:nlay], np.asarray(qsinv)[:nlay], np.asarray(per)[:nper], ilvry)
+    outs = [np.zeros(200, np.float32) for _ in range(4)]
+    ns = r["nsolved"]
+    if ilvry == 2:
+        outs[0][:ns] = r["u"][:ns]; outs[2][:ns] = r["c"][:ns]
+    else:
+        outs[1][:ns] = r["u"][:ns]; outs[3][:ns] = r["c"][:ns]
+    return tuple(outs)
+
+
+def forward_batch(model, periods, kind, nlay=None, nthreads=1):
+    """model float32 [B,5,L] rows (vp, vs, rho, h, qsinv) -> c[B,P], u[B,P], status[B]."""
+    model = np.ascontiguousarray(model, dtype=np.float32)
+    B, five, Lmax = model.shape
+    assert five == 5
+    per = _f32(periods); P = per.size
+    c = np.zeros((B, P), np.float32); u = np.zeros((B, P), np.float32)
+    status = np.zeros(B, np.int32)
+    nl = None
+    if nlay is not None:
+        nlay = np.ascontiguousarray(nlay, dtype=np.int32)
+        nl = nlay.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    lib().surfdisp_oracle_forward_batch(B, Lmax, nl, _fp(model), P, _fp(per), int(kind),
+                                        _fp(c), _fp(u),
+                                        status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                        int(nthreads))
+    return c, u, status

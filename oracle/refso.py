@@ -1,0 +1,89 @@
+"""ctypes loader for oracle/_ref/libfast_surf_ref.so  --  TEST INFRASTRUCTURE ONLY.
+
+The shared object is the *unmodified reference Fortran* (fast_surf_src/*.f) built
+by oracle/build_ref.sh with AMD flang.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; it is the checker / reported
+CPU baseline, never a product path.
+
+Calling convention = what f2py generates from fast_surf_src/fast_surf.pyf:6-19:
+all scalars by reference, float32 arrays, four zero-filled float32[200] outputs.
+
+"Fresh-process" semantics (defect 1): the Fortran keeps
+``ndiv`` in COMMON /c/ and clamps it in place (surfa.f:414-415, :783-784), so a
+solve depends on the history of the process.  ``fast_surf(..., fresh=True)``
+(the default) resets ndiv=5 (init.f:25 DATA value) and zeroes COMMON /dispe/
+(stale-output defect, calcul.f:173-189) before every call, which is exactly what
+a new process would see.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_ref", "libfast_surf_ref.so")
+_lib = None
+
+NPER_MAX = 200  # fast_surf.f:9 parameter nper=200
+
+
+def available() -> bool:
+    return os.path.exists(_SO)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            raise FileNotFoundError(
+                f"{_SO} missing: run oracle/build_ref.sh where /root/reference exists")
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _reset_state(L):
+    # COMMON /c/ nmax,mmax,kmax,idrop,iedit,ndiv,mode,fact,ra_1  (fast_surf.f:51)
+    c_blk = (ctypes.c_int32 * 9).in_dll(L, "c_")
+    c_blk[5] = 5
+    # COMMON /dispe/ per_R(200),per_L(200),uR(200,2),uL(200,2),cR(200,2),cL(200,2)
+    dispe = (ctypes.c_float * (200 * 10)).in_dll(L, "dispe_")
+    ctypes.memset(dispe, 0, ctypes.sizeof(dispe))
+
+
+def fast_surf(nlay, ilvry, vp, vs, rho, h, qsinv, per, nper, fresh=True):
+    """Reference fast_surf(): returns (ur0, ul0, cr0, cl0), float32[200] each."""
+    L = lib()
+    if fresh:
+        _reset_state(L)
+    f32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).astype(np.float32))
+    vp, vs, rho, h, qsinv = map(f32, (vp, vs, rho, h, qsinv))
+    for a in (vp, vs, rho, h, qsinv):
+        if a.size != nlay:
+            raise ValueError("layer arrays must have exactly nlay elements")
+    per200 = np.zeros(NPER_MAX, np.float32)
+    p = np.asarray(per, dtype=np.float64).astype(np.float32)
+    per200[: p.size] = p[:NPER_MAX]
+    outs = [np.zeros(NPER_MAX, np.float32) for _ in range(4)]
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    n_ = ctypes.c_int(int(nlay))
+    k_ = ctypes.c_int(int(ilvry))
+    np_ = ctypes.c_int(int(nper))
+    L.fast_surf_(ctypes.byref(n_), ctypes.byref(k_), fp(vp), fp(vs), fp(rho), fp(h),
+                 fp(qsinv), fp(per200), ctypes.byref(np_),
+                 fp(outs[0]), fp(outs[1]), fp(outs[2]), fp(outs[3]))
+    return tuple(outs)
+
+
+def forward_batch(vp, vs, rho, h, qsinv, periods, kind):
+    """Loop of reference calls over a [B, L] batch -> (c[B,P], u[B,P]) float32."""
+    vp = np.asarray(vp); B, Ln = vp.shape
+    P = len(periods)
+    c = np.zeros((B, P), np.float32); u = np.zeros((B, P), np.float32)
+    for i in range(B):
+        ur, ul, cr, cl = fast_surf(Ln, kind, vp[i], vs[i], rho[i], h[i], qsinv[i], periods, P)
+        if kind == 2:
+            c[i], u[i] = cr[:P], ur[:P]
+        else:
+            c[i], u[i] = cl[:P], ul[:P]
+    return c, u
