@@ -1,0 +1,50 @@
+"""Synthetic layered-earth stacks used by bench.py and the parity tests.
+
+Generator of SURVEY.md section 8(d): MCMC-like perturbed monotone stacks whose
+property rules follow the reference's layer classes (Vp = 1.76 Vs, layers.py:261;
+rho = 0.541 + 0.3601 Vp, layers.py:234; Qs = 600 / 150, layers.py:187,263).
+Pure numpy; no reference code involved.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+FIELDS = ("vp", "vs", "rho", "h", "qsinv")  # row order of a model[B,5,L] array
+                                            # = Fortran argument order a,b,rho,d,qs (fast_surf.f:2-5)
+
+
+def default_periods(P: int = 20) -> np.ndarray:
+    return np.linspace(8.0, 100.0, P).astype(np.float32)
+
+
+def synth_models(B: int, L: int, seed: int = 0, noise: float = 0.03, monotone: bool = True,
+                 total_thickness: float = 200.0) -> np.ndarray:
+    """float32 [B, 5, L] batch, rows (vp, vs, rho, h, qsinv); last layer = half-space."""
+    rng = np.random.default_rng(seed)
+    z = np.linspace(0.0, 1.0, L)
+    vs = 3.0 + 1.6 * z + rng.normal(0.0, noise, (B, L))
+    if monotone:
+        vs = np.sort(vs, axis=1)
+    h = np.full((B, L), total_thickness / L)
+    vp = 1.76 * vs
+    rho = 0.541 + 0.3601 * vp
+    qs = np.where(vs < 4.0, 600.0, 150.0)
+    return np.stack([vp, vs, rho, h, 1.0 / qs], axis=1).astype(np.float32)
+
+
+def water_models(B: int, seed: int = 5) -> np.ndarray:
+    """Ocean stacks with a water top layer, 9 layers."""
+    rng = np.random.default_rng(seed)
+    h = np.array([2, .5, 3.5, 3.5, 20, 30, 50, 80, 0.])
+    vs = np.array([0, 1.0, 3.3, 3.9, 4.4, 4.35, 4.4, 4.5, 4.6])
+    vp = 1.76 * vs
+    vp[0] = 1.475
+    vp[1] = 1.23 * vs[1] + 1.28
+    rho = 0.541 + 0.3601 * vp
+    rho[0] = 1.027
+    qs = np.array([1e4, 80, 350, 350, 150, 150, 150, 150, 150.])
+    m = np.stack([vp, vs, rho, h, 1.0 / qs])[None].astype(np.float32)
+    mm = np.repeat(m, B, 0)
+    mm[:, 1, 1:] += rng.normal(0, 0.05, (B, 8)).astype(np.float32)
+    mm[:, 3, 0] = rng.uniform(0.5, 4.5, B)
+    return mm
