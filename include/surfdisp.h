@@ -1,0 +1,103 @@
+/*
+ * surfdisp.h -- C ABI of libsurfdisp_hip.so: MI355X (gfx950) batched surface-wave
+ * dispersion forward solver, drop-in for pySurfInv's fast_surf() path.
+ *
+ * Boundary replaced (reference 001cat/pySurfInv):
+ *   - Fortran entry   SUBROUTINE FAST_SURF(n_layer0,kind0,a_ref0,b_ref0,rho_ref0,d_ref0,
+ *                     qs_ref0,cvper,ncvper,uR0,uL0,cR0,cL0)      fast_surf_src/fast_surf.f:2-5
+ *   - f2py signature  fast_surf(nlay,ilvry,Vp,Vs,rho,h,qsinv,per,nper)->(ur0,ul0,cr0,cl0)
+ *                                                                 fast_surf_src/fast_surf.pyf:6-19
+ *   - call sites      models.py:27 (_calForward), senskernel.py:188 (SensKernelPert._forward)
+ *
+ * Plain pointers and sizes only; no torch / C++ types.  All entry points are reentrant
+ * (the reference is not: COMMON state, fast_surf.f:48-71).
+ *
+ * Conventions kept from the reference:
+ *   - argument order (Vp, Vs, rho, h, 1/Qs)                       fast_surf.f:2-5,44-45
+ *   - kind / ilvry: 1 = Love, 2 = Rayleigh                        models.py:13-16
+ *   - last layer is the half-space, its thickness is ignored       flat1.f:69
+ *   - a top layer with Vs < 0.1 is water                          fast_surf.f:158,171
+ *   - no exceptions: unsolved periods are 0 in c and U             fast_surf.f:197, calcul.f:203-219
+ *   - periods must be ascending; outputs depend on the period LIST (mmax carry-over,
+ *     start rule c1 = 0.9*c(k-1): calcul.f:112,133,143)
+ *   - "fresh process" state for every solve (ndiv = 5, init.f:25)
+ */
+#ifndef SURFDISP_H
+#define SURFDISP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SURFDISP_ABI_VERSION 1
+#define SURFDISP_NPER_MAX 200      /* fast_surf.pyf:14-19: cvper and outputs are real*4[200] */
+#define SURFDISP_NLAY_MAX 200      /* layers per stack accepted by this library */
+
+#define SURFDISP_KIND_LOVE     1   /* == reference kind0 / ilvry */
+#define SURFDISP_KIND_RAYLEIGH 2
+
+/* per-model status word (the explicit form of the reference's "zeros in c") */
+enum {
+    SURFDISP_OK         = 0,   /* all P periods solved */
+    SURFDISP_PARTIAL    = 1,   /* bracketing failed at period k>1: c,U of periods k..P are 0 (calcul.f:203,218-219) */
+    SURFDISP_NOROOT     = 2,   /* bracketing failed at the first period: everything 0 (calcul.f:203-212) */
+    SURFDISP_BADMODEL   = 4    /* nlay < 2, nlay > Lmax, or non-finite input: everything 0 */
+};
+
+/* return codes */
+enum {
+    SURFDISP_SUCCESS        = 0,
+    SURFDISP_ERR_INVALID    = -1,  /* bad argument (NULL pointer, B<1, P<1 or >200, kind, L range) */
+    SURFDISP_ERR_NO_DEVICE  = -2,  /* no gfx950 device / HIP runtime unavailable -- there is NO CPU fallback */
+    SURFDISP_ERR_HIP        = -3,  /* a HIP call failed; see surfdisp_last_error() */
+    SURFDISP_ERR_WORKSPACE  = -4   /* workspace too small */
+};
+
+/* ---- (1) Fortran-ABI drop-in: same symbol name and by-reference convention as the object the
+ *          reference builds from fast_surf.f:2-5 (gfortran / flang lower-case + underscore).
+ *          Runs ONE stack through the GPU path.  uR/uL/cR/cL are float[200]; only the pair that
+ *          matches *kind is written, and only its first imax entries (fast_surf.f:197-208) --
+ *          the caller pre-zeroes them exactly as f2py does (intent(out) arrays are zero-filled). */
+void fast_surf_(const int *n_layer, const int *kind,
+                const float *vp, const float *vs, const float *rho,
+                const float *h, const float *qsinv,
+                const float *per /*[200]*/, const int *nper,
+                float *uR, float *uL, float *cR, float *cL);
+
+/* ---- (2) batched solve, host buffers.
+ *   model  [B][5][Lmax]  rows = vp, vs, rho, h, qsinv (the five fast_surf.f:2-5 layer arrays)
+ *   nlay   [B] or NULL (every stack has Lmax layers); unused tail entries of a row are ignored
+ *   per    [P] ascending periods (s);   kind = 1 Love | 2 Rayleigh
+ *   c, u   [B][P] phase / group velocity (km/s), 0 where unsolved;  status [B] or NULL
+ * Copies in, runs the kernels on `device`, copies out.  Returns SURFDISP_SUCCESS or an error. */
+int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const float *model,
+                           int P, const float *per, int kind,
+                           float *c, float *u, int *status);
+
+/* ---- (3) batched solve, DEVICE pointers, stream-ordered, no allocation, no host sync:
+ *          safe to capture in a hipGraph.  `stream` is a hipStream_t (NULL = default stream).
+ *          `workspace` = device buffer of at least surfdisp_workspace_bytes(B, Lmax, P) bytes.
+ *          All pointers (nlay, model, per, c, u, status, workspace) are device pointers on the
+ *          current device.  nlay and status may be NULL. */
+size_t surfdisp_workspace_bytes(int B, int Lmax, int P);
+int surfdisp_forward_batch_device(void *stream, int B, int Lmax, const int *nlay,
+                                  const float *model, int P, const float *per, int kind,
+                                  float *c, float *u, int *status,
+                                  void *workspace, size_t workspace_bytes);
+
+/* ---- tuning / introspection ------------------------------------------------------------- */
+/* lanes of one wavefront that cooperate on one stack's root search (1,2,4,...,64); 0 = choose
+ * from (B, Lmax).  Also settable through the environment variable SURFDISP_TEAM. */
+int  surfdisp_set_team(int lanes);
+int  surfdisp_get_team(int B, int Lmax);           /* what a launch with (B, Lmax) would use */
+int  surfdisp_device_count(void);                  /* gfx950 devices visible; <=0: none */
+int  surfdisp_abi_version(void);
+const char *surfdisp_last_error(void);             /* thread-local, never NULL */
+const char *surfdisp_kernel_name(int which);       /* 0 prep, 1 phase (root search), 2 group */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SURFDISP_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of libsurfdisp_hip.so (C ABI: include/surfdisp.h).
+
+There is no CPU fallback in this package: if the HIP library is missing, or no
+gfx950 device is present, every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsurfdisp_hip.so")
+
+SUCCESS, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_WORKSPACE = 0, -1, -2, -3, -4
+OK, PARTIAL, NOROOT, BADMODEL = 0, 1, 2, 4
+KIND_LOVE, KIND_RAYLEIGH = 1, 2
+NPER_MAX, NLAY_MAX = 200, 200
+
+# every symbol include/surfdisp.h declares
+EXPORTS = (
+    "fast_surf_", "surfdisp_forward_batch", "surfdisp_workspace_bytes",
+    "surfdisp_forward_batch_device", "surfdisp_set_team", "surfdisp_get_team",
+    "surfdisp_device_count", "surfdisp_abi_version", "surfdisp_last_error",
+    "surfdisp_kernel_name",
+)
+
+
+class SurfdispError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library; raises SurfdispError (never falls back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SurfdispError(
+            f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). pysurfinv_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    fp = ctypes.POINTER(ctypes.c_float)
+    ip = ctypes.POINTER(ctypes.c_int)
+    vp = ctypes.c_void_p
+    L.fast_surf_.restype = None
+    L.fast_surf_.argtypes = [ip, ip, fp, fp, fp, fp, fp, fp, ip, fp, fp, fp, fp]
+    L.surfdisp_forward_batch.restype = ctypes.c_int
+    L.surfdisp_forward_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, fp,
+                                         ctypes.c_int, fp, ctypes.c_int, fp, fp, ip]
+    L.surfdisp_workspace_bytes.restype = ctypes.c_size_t
+    L.surfdisp_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.surfdisp_forward_batch_device.restype = ctypes.c_int
+    L.surfdisp_forward_batch_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp,
+                                                ctypes.c_int, vp, ctypes.c_int, vp, vp, vp,
+                                                vp, ctypes.c_size_t]
+    L.surfdisp_set_team.restype = ctypes.c_int
+    L.surfdisp_set_team.argtypes = [ctypes.c_int]
+    L.surfdisp_get_team.restype = ctypes.c_int
+    L.surfdisp_get_team.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.surfdisp_device_count.restype = ctypes.c_int
+    L.surfdisp_abi_version.restype = ctypes.c_int
+    L.surfdisp_last_error.restype = ctypes.c_char_p
+    L.surfdisp_kernel_name.restype = ctypes.c_char_p
+    L.surfdisp_kernel_name.argtypes = [ctypes.c_int]
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != SUCCESS:
+        msg = lib().surfdisp_last_error().decode(errors="replace")
+        raise SurfdispError(f"libsurfdisp_hip error {rc}: {msg}")

@@ -1,0 +1,239 @@
+// surfdisp_capi.hip -- the C ABI of libsurfdisp_hip.so (declared in include/surfdisp.h).
+// Host-side only: argument checking, workspace carving, stream-ordered launches.  There is no
+// CPU fallback: without a HIP device every entry point fails with SURFDISP_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "surfdisp_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+int g_team_override = 0;
+
+void set_err(const char *fmt, const char *a = "", const char *b = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+}
+
+#define SD_HIP(call)                                                         \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) {                                              \
+            set_err("%s failed: %s", #call, hipGetErrorString(e_));          \
+            return SURFDISP_ERR_HIP;                                         \
+        }                                                                    \
+    } while (0)
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct Carve {
+    float *mdl, *ratio;
+    int *nl, *nsolved;
+    size_t total;
+};
+
+Carve carve(void *base, int B, int Lmax, int P)
+{
+    char *p = static_cast<char *>(base);
+    size_t off = 0;
+    Carve c;
+    c.mdl = reinterpret_cast<float *>(p + off);     off += align_up((size_t)10 * Lmax * B * sizeof(float));
+    c.ratio = reinterpret_cast<float *>(p + off);   off += align_up((size_t)P * B * sizeof(float));
+    c.nl = reinterpret_cast<int *>(p + off);        off += align_up((size_t)B * sizeof(int));
+    c.nsolved = reinterpret_cast<int *>(p + off);   off += align_up((size_t)B * sizeof(int));
+    c.total = off;
+    return c;
+}
+
+int pick_team(int B, int Lmax)
+{
+    int G = g_team_override;
+    if (G == 0) {
+        const char *e = getenv("SURFDISP_TEAM");
+        if (e) G = atoi(e);
+    }
+    if (G == 0) {
+        // aim for >= 4 wavefronts per SIMD on 256 CUs x 4 SIMDs (262 144 lanes)
+        G = 1;
+        while (G < 64 && (long)B * G < 262144L) G *= 2;
+    }
+    if (G < 1) G = 1;
+    if (G > 64) G = 64;
+    int p2 = 1;
+    while (p2 * 2 <= G) p2 *= 2;
+    G = p2;
+    // working stack of 256/G teams must fit LDS; keep <= 80 KB so two workgroups share a CU
+    while (G < 64 && sd::phase_lds_bytes(Lmax, G) > 80u * 1024u) G *= 2;
+    return G;
+}
+
+int check_args(int B, int Lmax, int P, int kind, const void *model, const void *per,
+               const void *c, const void *u)
+{
+    if (B < 1 || Lmax < 2 || Lmax > SURFDISP_NLAY_MAX || P < 1 || P > SURFDISP_NPER_MAX ||
+        (kind != SURFDISP_KIND_LOVE && kind != SURFDISP_KIND_RAYLEIGH) || !model || !per || !c || !u) {
+        set_err("invalid argument (B>=1, 2<=Lmax<=200, 1<=P<=200, kind 1|2, non-null buffers)");
+        return SURFDISP_ERR_INVALID;
+    }
+    return SURFDISP_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+int surfdisp_abi_version(void) { return SURFDISP_ABI_VERSION; }
+
+const char *surfdisp_last_error(void) { return g_err; }
+
+const char *surfdisp_kernel_name(int which)
+{
+    switch (which) {
+        case 0: return "surfdisp_prep_kernel";
+        case 1: return "surfdisp_phase_kernel";
+        case 2: return "surfdisp_group_kernel";
+        default: return "";
+    }
+}
+
+int surfdisp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int surfdisp_set_team(int lanes)
+{
+    if (lanes < 0 || lanes > 64 || (lanes & (lanes - 1))) {
+        set_err("team must be 0 or a power of two <= 64");
+        return SURFDISP_ERR_INVALID;
+    }
+    g_team_override = lanes;
+    return SURFDISP_SUCCESS;
+}
+
+int surfdisp_get_team(int B, int Lmax) { return pick_team(B, Lmax); }
+
+size_t surfdisp_workspace_bytes(int B, int Lmax, int P)
+{
+    if (B < 1 || Lmax < 2 || P < 1) return 0;
+    return carve(nullptr, B, Lmax, P).total;
+}
+
+int surfdisp_forward_batch_device(void *stream, int B, int Lmax, const int *nlay,
+                                  const float *model, int P, const float *per, int kind,
+                                  float *c, float *u, int *status,
+                                  void *workspace, size_t workspace_bytes)
+{
+    int rc = check_args(B, Lmax, P, kind, model, per, c, u);
+    if (rc) return rc;
+    if (!workspace || workspace_bytes < surfdisp_workspace_bytes(B, Lmax, P)) {
+        set_err("workspace too small");
+        return SURFDISP_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Carve w = carve(workspace, B, Lmax, P);
+    const int G = pick_team(B, Lmax);
+
+    sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl};
+    SD_HIP(sd::launch_prep(s, kind, pa));
+    float wtol = 3.2e-4f;
+    if (const char *e = getenv("SURFDISP_WTOL")) wtol = (float)atof(e);
+    sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, c, w.ratio, w.nsolved, status, wtol};
+    SD_HIP(sd::launch_phase(s, kind, G, ph));
+    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, c, w.ratio, w.nsolved, u};
+    SD_HIP(sd::launch_group(s, kind, ga));
+    return SURFDISP_SUCCESS;
+}
+
+int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const float *model,
+                           int P, const float *per, int kind,
+                           float *c, float *u, int *status)
+{
+    int rc = check_args(B, Lmax, P, kind, model, per, c, u);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        set_err("no HIP device: libsurfdisp_hip has no CPU fallback");
+        return SURFDISP_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { set_err("bad device ordinal"); return SURFDISP_ERR_INVALID; }
+    SD_HIP(hipSetDevice(device));
+    const size_t nm = (size_t)B * 5 * Lmax * sizeof(float);
+    const size_t no = (size_t)B * P * sizeof(float);
+    const size_t ws = surfdisp_workspace_bytes(B, Lmax, P);
+    char *d = nullptr;
+    const size_t o_model = 0;
+    const size_t o_per = o_model + align_up(nm);
+    const size_t o_c = o_per + align_up((size_t)P * sizeof(float));
+    const size_t o_u = o_c + align_up(no);
+    const size_t o_st = o_u + align_up(no);
+    const size_t o_nl = o_st + align_up((size_t)B * sizeof(int));
+    const size_t o_ws = o_nl + align_up((size_t)B * sizeof(int));
+    SD_HIP(hipMalloc(reinterpret_cast<void **>(&d), o_ws + ws));
+    hipStream_t s = nullptr;
+    int ret = SURFDISP_SUCCESS;
+    do {
+        if (hipMemcpyAsync(d + o_model, model, nm, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(d + o_per, per, (size_t)P * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess ||
+            (nlay && hipMemcpyAsync(d + o_nl, nlay, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess)) {
+            set_err("host->device copy failed"); ret = SURFDISP_ERR_HIP; break;
+        }
+        ret = surfdisp_forward_batch_device(s, B, Lmax, nlay ? reinterpret_cast<int *>(d + o_nl) : nullptr,
+                                            reinterpret_cast<float *>(d + o_model), P,
+                                            reinterpret_cast<float *>(d + o_per), kind,
+                                            reinterpret_cast<float *>(d + o_c),
+                                            reinterpret_cast<float *>(d + o_u),
+                                            reinterpret_cast<int *>(d + o_st), d + o_ws, ws);
+        if (ret) break;
+        if (hipMemcpyAsync(c, d + o_c, no, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(u, d + o_u, no, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            (status && hipMemcpyAsync(status, d + o_st, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess)) {
+            set_err("device->host copy failed"); ret = SURFDISP_ERR_HIP; break;
+        }
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { set_err("kernel execution failed: %s", hipGetErrorString(e)); ret = SURFDISP_ERR_HIP; }
+    } while (0);
+    (void)hipFree(d);
+    return ret;
+}
+
+// Fortran-ABI drop-in for the reference object's symbol (fast_surf.f:2-5).
+void fast_surf_(const int *n_layer, const int *kind,
+                const float *vp, const float *vs, const float *rho,
+                const float *h, const float *qsinv,
+                const float *per, const int *nper,
+                float *uR, float *uL, float *cR, float *cL)
+{
+    if (!n_layer || !kind || !nper || !vp || !vs || !rho || !h || !qsinv || !per) return;
+    const int n = *n_layer, P = *nper > SURFDISP_NPER_MAX ? SURFDISP_NPER_MAX : *nper;  // init.f:63-66
+    if (n < 2 || n > SURFDISP_NLAY_MAX || P < 1) { set_err("fast_surf_: bad n_layer/nper"); return; }
+    float *model = static_cast<float *>(malloc((size_t)5 * n * sizeof(float)));
+    float c[SURFDISP_NPER_MAX], u[SURFDISP_NPER_MAX];
+    if (!model) return;
+    memcpy(model + 0 * n, vp, n * sizeof(float));
+    memcpy(model + 1 * n, vs, n * sizeof(float));
+    memcpy(model + 2 * n, rho, n * sizeof(float));
+    memcpy(model + 3 * n, h, n * sizeof(float));
+    memcpy(model + 4 * n, qsinv, n * sizeof(float));
+    int dev = 0;
+    if (const char *e = getenv("SURFDISP_DEVICE")) dev = atoi(e);
+    const int rc = surfdisp_forward_batch(dev, 1, n, nullptr, model, P, per, *kind, c, u, nullptr);
+    free(model);
+    if (rc != SURFDISP_SUCCESS) {
+        // no silent fallback: report loudly and leave the outputs untouched (= all zeros = failure
+        // in the reference's convention, models.py:29-33)
+        fprintf(stderr, "surfdisp fast_surf_: %s\n", g_err);
+        return;
+    }
+    for (int i = 0; i < P; ++i) {                       // fast_surf.f:197-208
+        if (c[i] == 0.0f) break;
+        if (*kind == SURFDISP_KIND_LOVE) { if (cL) cL[i] = c[i]; if (uL) uL[i] = u[i]; }
+        else                             { if (cR) cR[i] = c[i]; if (uR) uR[i] = u[i]; }
+    }
+}
+
+}  // extern "C"

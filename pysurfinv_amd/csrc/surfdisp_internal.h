@@ -1,0 +1,46 @@
+// surfdisp_internal.h -- kernel argument blocks and launch prototypes shared by
+// surfdisp_kernels.hip and surfdisp_capi.hip.  Not part of the public ABI (include/surfdisp.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "surfdisp.h"
+
+namespace sd {
+
+struct PrepArgs {
+    int B, Lmax;
+    const int *nlay;      // [B] or nullptr
+    const float *model;   // [B][5][Lmax] (vp, vs, rho, h, qsinv) as handed over by the caller
+    float *mdl;           // [10][Lmax][B] SoA: the five inputs + five flattening factors
+    int *nl;              // [B] validated layer count, 0 = bad model
+};
+
+struct PhaseArgs {
+    int B, Lmax, P;
+    const float *mdl;
+    const int *nl;
+    const float *per;     // [P]
+    float *c;             // [B][P]
+    float *ratio;         // [P][B] ellipticity (Rayleigh), input of the group-velocity kernel
+    int *nsolved;         // [B]
+    int *status;          // [B] or nullptr
+    float wtol;           // bracket width below which the root is read off by a secant step
+};
+
+struct GroupArgs {
+    int B, Lmax, P;
+    const float *mdl;
+    const int *nl;
+    const float *per;
+    const float *c;
+    const float *ratio;
+    const int *nsolved;
+    float *u;             // [B][P]
+};
+
+size_t phase_lds_bytes(int Lmax, int G);
+hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a);
+hipError_t launch_phase(hipStream_t s, int kind, int G, const PhaseArgs &a);
+hipError_t launch_group(hipStream_t s, int kind, const GroupArgs &a);
+
+}  // namespace sd

@@ -1,0 +1,911 @@
+// surfdisp_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4).
+//
+// Batched surface-wave dispersion forward solver: the GPU counterpart of the reference's
+// fast_surf() path (001cat/pySurfInv fast_surf_src/{fast_surf,init,calcul,flat1,surfa}.f).
+// This is NOT a translation of the Fortran: the work decomposition, data layout and the
+// root-refinement scheme are designed for 64-wide wavefronts; the reference is cited where a
+// formula or a semantic rule is taken from it.
+//
+// Pipeline for one (batch, wave type):
+//   K0 surfdisp_prep_kernel   : AoS model[B][5][L] -> SoA mdl[10][L][B]; per-layer earth-flattening
+//                               factors computed ONCE per stack (flat1.f:33-69 recomputes them
+//                               40x per solve), validation.
+//   K1 surfdisp_phase_kernel  : phase velocities.  A TEAM of G lanes (G = 1..64, one wavefront holds
+//                               64/G teams) owns one stack; its period-dependent working stack
+//                               (a, b, rho, d) lives in LDS; every loop iteration each lane evaluates
+//                               the secular function at its own trial velocity with the 5-component
+//                               (Rayleigh) or 2-component (Love) recursion state in registers.
+//                               Periods are walked in order inside the team (faithful start rule
+//                               c1 = 0.9*c(k-1), mmax carry-over, failure guards: calcul.f:104-220).
+//   K2 surfdisp_group_kernel  : group velocities, one lane per (stack, period): eigenfunction
+//                               integration + energy integrals (surfa.f:714-1192 / 374-606), fp64 state
+//                               for Rayleigh as in the reference (surfa.f:717-722).
+// No MFMA: the products are 5x5 / 4x4 / 2x2.  HBM traffic is one read of the model array and one
+// write of c/U; everything else is VALU + transcendental work.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "surfdisp_internal.h"
+
+namespace sd {
+
+// ---- reference constants ---------------------------------------------------------------------
+__device__ constexpr float R0      = 6371.0f;       // flat1.f:21
+__device__ constexpr float PI_REF  = 3.1415927f;    // calcul.f:32, fast_surf.f:77
+__device__ constexpr float DC      = 0.01f;         // init.f:25
+__device__ constexpr float FACT    = 4.0f;          // init.f:25
+__device__ constexpr float ACCUR   = 1.e-8f;        // surfa.f:191-192
+
+// SoA field ids of mdl[NF][Lmax][B]
+enum { F_VP = 0, F_VS, F_RHO, F_H, F_QS, F_DIF, F_QQQ, F_DFL, F_HSF, F_HSR, NF = 10 };
+
+__device__ __forceinline__ float pwr_of(int kind) { return kind == 1 ? 5.0f : 2.2750f; }  // flat1.f:27-28
+
+// =================================================================================== K0: prep
+// One lane per stack.  Flattening factors depend only on the radii, i.e. on the thickness prefix
+// sums (flat1.f:33-37), not on the period or on how many layers are flattened:
+//   regular layer i : dif_i, qqq_i (flat1.f:44-56), new thickness z1(i+1)-z1(i) (flat1.f:65-68)
+//   layer i used as half space: hsf_i = a/r_i, hsr_i = (1/hsf_i)^pwr (flat1.f:58-62)
+template <int KIND>
+__global__ __launch_bounds__(256) void surfdisp_prep_kernel(PrepArgs A)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= A.B) return;
+    const int Lmax = A.Lmax, B = A.B;
+    int n = A.nlay ? A.nlay[b] : Lmax;
+    const float *src = A.model + (size_t)b * 5 * Lmax;
+    float *mdl = A.mdl;
+    bool ok = (n >= 2) && (n <= Lmax);
+    const float pwr = pwr_of(KIND);
+    const float apw = powf(R0, pwr);
+    if (ok) {
+        float hs = 0.0f;          // running thickness sum, fp32 in layer order (flat1.f:33-37)
+        float r_i = R0;           // radius of the top of layer i
+        float z_i = 0.0f;         // flattened depth of the top of layer i
+        for (int i = 0; i < n; ++i) {
+            const float vp = src[0 * Lmax + i], vs = src[1 * Lmax + i], rho = src[2 * Lmax + i];
+            const float h = src[3 * Lmax + i], qs = src[4 * Lmax + i];
+            if (!(isfinite(vp) && isfinite(vs) && isfinite(rho) && isfinite(h) && isfinite(qs)) ||
+                !(vp > 0.0f) || !(rho > 0.0f) || (vs < 0.0f) || (h < 0.0f))
+                ok = false;
+            hs = hs + h;
+            const float r_n = R0 - hs;                       // radius of the bottom of layer i
+            float dif = 0.0f, qqq = 0.0f, dfl = 0.0f;
+            if (i < n - 1) {
+                const float fltd = logf(r_i / r_n);
+                dif = (1.0f / r_n - 1.0f / r_i) * R0 / fltd;
+                const float difr = powf(r_i, pwr) - powf(r_n, pwr);
+                qqq = difr / (fltd * apw * pwr);
+                const float z_n = R0 * logf(R0 / r_n);
+                dfl = z_n - z_i;
+                z_i = z_n;
+                if (!(r_n > 0.0f) || !isfinite(dif) || !isfinite(qqq)) ok = false;
+            }
+            const float hsf = R0 / r_i;
+            const float hsr = powf(1.0f / hsf, pwr);
+            const size_t o = (size_t)i * B + b;
+            const size_t fs = (size_t)Lmax * B;
+            mdl[F_VP * fs + o] = vp;   mdl[F_VS * fs + o] = vs;   mdl[F_RHO * fs + o] = rho;
+            mdl[F_H * fs + o] = h;     mdl[F_QS * fs + o] = qs;
+            mdl[F_DIF * fs + o] = dif; mdl[F_QQQ * fs + o] = qqq; mdl[F_DFL * fs + o] = dfl;
+            mdl[F_HSF * fs + o] = hsf; mdl[F_HSR * fs + o] = hsr;
+            r_i = r_n;
+        }
+    }
+    A.nl[b] = ok ? n : 0;          // 0 => BADMODEL: K1/K2 write zeros
+}
+
+// per-period, per-layer working values (calcul.f:112-131 then flat1 with n_flat layers)
+struct LayerV { float a, b, rho, d; };
+
+__device__ __forceinline__ LayerV layer_at(const float *__restrict__ mdl, size_t fs, size_t o,
+                                           float lnT, bool is_halfspace)
+{
+    const float a_ref = mdl[F_VP * fs + o], b_ref = mdl[F_VS * fs + o];
+    const float rho_ref = mdl[F_RHO * fs + o], qs = mdl[F_QS * fs + o];
+    const float qsq = qs * lnT / PI_REF;                                   // calcul.f:122
+    const float qpq = qsq * 1.33333333f * (b_ref * b_ref) / (a_ref * a_ref); // calcul.f:123
+    float bb = b_ref * (1.0f + qsq);
+    float aa = a_ref * (1.0f + qpq);
+    LayerV v;
+    if (!is_halfspace) {
+        const float dif = mdl[F_DIF * fs + o];
+        v.a = aa * dif; v.b = bb * dif;
+        v.rho = rho_ref * mdl[F_QQQ * fs + o];
+        v.d = mdl[F_DFL * fs + o];
+    } else {
+        const float hsf = mdl[F_HSF * fs + o];
+        v.a = aa * hsf; v.b = bb * hsf;
+        v.rho = rho_ref * mdl[F_HSR * fs + o];
+        v.d = 0.0f;
+    }
+    return v;
+}
+
+// ================================================================ secular functions (registers)
+// LDS working stack of one team: w[(f*Lcap + m)*S + slot], f = 0..3 (a, b, rho, d)
+#define W_A(m) wq[((0 * Lcap + (m)) * S)]
+#define W_B(m) wq[((1 * Lcap + (m)) * S)]
+#define W_R(m) wq[((2 * Lcap + (m)) * S)]
+#define W_D(m) wq[((3 * Lcap + (m)) * S)]
+
+// Rayleigh: Dunkin compound-matrix recursion, surfa.f:193-357.  start = 1 -> dispersion
+// (returns -bb1, surfa.f:357); start = 2/3 -> the two ellipticity passes (returns bb1, surfa.f:360-363).
+__device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap, const int S,
+                                                const int mmax, const float c, const float T,
+                                                const int start)
+{
+    const float wvno = 6.28318531f / (c * T);
+    const float csq = c * c;
+    float b1 = (start == 1) ? 1.0f : 0.0f, b2 = (start == 2) ? 1.0f : 0.0f,
+          b3 = (start == 3) ? 1.0f : 0.0f, b4 = 0.0f, b5 = 0.0f;
+    for (int m = 0; m < mmax - 1; ++m) {
+        const float pv = W_A(m), sv = W_B(m), rho = W_R(m), d = W_D(m);
+        const float arga = 1.0f - csq / (pv * pv);
+        float ra = sqrtf(fabsf(arga));
+        if (arga > 0.0f) ra = -ra;
+        float a11, a12, a13, a14, a15, a21, a22, a23, a24, a31, a32, a33, a41, a42, a51;
+        if (!(fabsf(sv) > ACCUR)) {
+            // liquid surface layer, surfa.f:216-251 (skipped entirely in the ellipticity passes)
+            if (start != 1) continue;
+            const float pm = wvno * ra * d;
+            const float rhoc = rho * csq;
+            float sinpr, cosp;
+            if (fabsf(ra) < ACCUR) { sinpr = wvno * d; cosp = 1.0f; }
+            else if (ra < 0.0f) {
+                const float ep = expf(pm), em = expf(-pm);
+                sinpr = (ep - em) / (2.0f * ra);
+                cosp = 0.5f * (ep + em);
+            } else {
+                float sn, cs; sincosf(pm, &sn, &cs);
+                sinpr = sn / ra; cosp = cs;
+            }
+            // only a11 and a21 are non-zero (surfa.f:236-250)
+            const float n1 = cosp * b1;
+            const float n2 = rhoc * sinpr * b1;
+            const float n5 = cosp * b5 - rhoc * sinpr * b4;
+            b1 = n1; b2 = n2; b3 = 0.0f; b4 = 0.0f; b5 = n5;
+            continue;
+        }
+        const float argb = 1.0f - csq / (sv * sv);
+        float rb = sqrtf(fabsf(argb));
+        if (argb > 0.0f) rb = -rb;
+        const float g = 2.0f * (sv * sv) / csq;
+        const float g1 = g - 1.0f;
+        const float rhoc = rho * csq;
+        const float pm = wvno * ra * d;
+        const float qm = wvno * rb * d;
+        float rsinp, sinpr, cosp, rsinq, sinqr, cosq;
+        if (ra < 0.0f) {                                   // evanescent P, surfa.f:267-269
+            const float ep = expf(pm), em = expf(-pm);
+            rsinp = -ra * 0.5f * (ep - em);
+            sinpr = -rsinp / (ra * ra);
+            cosp = 0.5f * (ep + em);
+        } else if (ra == 0.0f) {
+            rsinp = 0.0f; sinpr = wvno * d; cosp = 1.0f;
+        } else {                                           // oscillatory P, surfa.f:271-273
+            float sn, cs; sincosf(pm, &sn, &cs);
+            rsinp = ra * sn; sinpr = rsinp / (ra * ra); cosp = cs;
+        }
+        if (fabsf(rb) < ACCUR) {
+            rsinq = 0.0f; sinqr = wvno * d; cosq = 1.0f;
+        } else if (rb > 0.0f) {
+            float sn, cs; sincosf(qm, &sn, &cs);
+            rsinq = rb * sn; sinqr = rsinq / (rb * rb); cosq = cs;
+        } else {
+            const float ep = expf(qm), em = expf(-qm);
+            rsinq = -rb * 0.5f * (ep - em);
+            sinqr = -rsinq / (rb * rb);
+            cosq = 0.5f * (ep + em);
+        }
+        {   // the fifteen distinct entries, surfa.f:289-320
+            const float rr = rsinp * rsinq, ss = sinpr * sinqr, cc = cosp * cosq;
+            const float rs1 = rsinp * cosq, rs2 = sinqr * cosp, rs3 = sinpr * cosq, rs4 = rsinq * cosp;
+            const float gm = 2.0f * g - 1.0f;
+            const float gs = g * g, g1s = g1 * g1;
+            const float ccm = 1.0f - cc;
+            const float gg1 = g * g1;
+            const float rhocs = rhoc * rhoc;
+            const float suu = gs * rr + g1s * ss;
+            a11 = (2.0f * gs - gm) * cc - suu - 2.0f * gg1;
+            a12 = -(rs1 + rs2) / rhoc;
+            a13 = -2.0f * (gm * ccm + g1 * ss + g * rr) / rhoc;
+            a14 = (rs3 + rs4) / rhoc;
+            a15 = (2.0f * ccm + rr + ss) / rhocs;
+            a21 = rhoc * (g1s * rs3 + gs * rs4);
+            a22 = cc;
+            a23 = 2.0f * (g * rs4 + g1 * rs3);
+            a24 = sinpr * rsinq;
+            a31 = rhoc * (gg1 * gm * ccm + g1s * g1 * ss + gs * g * rr);
+            a32 = g1 * rs2 + g * rs1;
+            a33 = 1.0f + 2.0f * (2.0f * gg1 * ccm + suu);
+            a41 = -rhoc * (g1s * rs2 + gs * rs1);
+            a42 = rsinp * sinqr;
+            a51 = rhocs * (2.0f * gs * g1s * ccm + gs * gs * rr + g1s * g1s * ss);
+        }
+        // compound-matrix product with its symmetries, surfa.f:326-330
+        const float n1 = a11 * b1 + a12 * b2 + a13 * b3 + a14 * b4 + a15 * b5;
+        const float n2 = a21 * b1 + a22 * b2 + a23 * b3 + a24 * b4 - a14 * b5;
+        const float n3 = a31 * b1 + a32 * b2 + a33 * b3 - 0.5f * a23 * b4 + 0.5f * a13 * b5;
+        const float n4 = a41 * b1 + a42 * b2 - 2.0f * a32 * b3 + a22 * b4 - a12 * b5;
+        const float n5 = a51 * b1 - a41 * b2 + 2.0f * a31 * b3 - a21 * b4 + a11 * b5;
+        b1 = n1; b2 = n2; b3 = n3; b4 = n4; b5 = n5;
+    }
+    // half-space closure, surfa.f:340-354
+    const int mh = mmax - 1;
+    const float pp = W_A(mh), sv = W_B(mh), rho = W_R(mh);
+    const float arga = 1.0f - csq / (pp * pp);
+    float ra = sqrtf(fabsf(arga));
+    if (arga > 0.0f) ra = -ra;
+    const float argb = 1.0f - csq / (sv * sv);
+    float rb = sqrtf(fabsf(argb));
+    if (argb > 0.0f) rb = -rb;
+    const float g = 2.0f * (sv * sv) / csq;
+    const float g1 = g - 1.0f;
+    const float sss = sv * sv, ppp = pp * pp, rhp = rho * pp, gra = g * ra, g1s = g1 * g1;
+    const float rba = rb - 1.0f / ra;
+    const float h11 = -2.0f * rb * sss / ppp + csq * g1s / ppp / gra;
+    const float t12 = rhp * pp;
+    const float h13 = -rb / t12 + g1 / t12 / gra;
+    const float h14 = rb / t12 / gra;
+    const float h15 = rba / rhp / rhp / csq / g;
+    const float h12 = -1.0f / g / t12;
+    const float bb1 = h11 * b1 + h12 * b2 + 2.0f * h13 * b3 + h14 * b4 + h15 * b5;
+    return (start == 1) ? -bb1 : bb1;
+}
+
+// Love: Thomson-Haskell 2-vector from the half space up, surfa.f:143-179.
+__device__ __forceinline__ float delta_love(const float *wq, const int Lcap, const int S,
+                                            const int mmax, const float c, const float T)
+{
+    const float wvno = 6.2831853f / (c * T);
+    const int mh = mmax - 1;
+    float bm = W_B(mh);
+    float covb = c / bm;
+    float h = W_R(mh) * bm * bm;
+    float rb = sqrtf(fabsf(covb * covb - 1.0f));
+    float ut = 1.0f, tt = h * rb;
+    for (int m = mh - 1; m >= 0; --m) {
+        bm = W_B(m);
+        if (bm == 0.0f) continue;                          // water, surfa.f:152
+        const float d = W_D(m);
+        covb = c / bm;
+        rb = sqrtf(fabsf(covb * covb - 1.0f));
+        h = W_R(m) * bm * bm;
+        const float q = -wvno * d * rb;
+        float y, z, cosq;
+        if (rb < 0.1e-20f || c == bm) { y = -wvno * d; z = 0.0f; cosq = 1.0f; }
+        else if (c < bm) {
+            const float ep = expf(q), em = 1.0f / ep;
+            y = (ep - em) / (2.0f * rb);
+            z = -rb * rb * y;
+            cosq = (ep + em) / 2.0f;
+        } else {
+            float sn, cs; sincosf(q, &sn, &cs);
+            y = sn / rb; z = rb * sn; cosq = cs;
+        }
+        const float eut = cosq * ut - y * tt / h;
+        const float ett = h * z * ut + cosq * tt;
+        ut = eut; tt = ett;
+    }
+    return -tt;
+}
+
+// layer dropping for one trial velocity, surfa.f:94-105
+__device__ __forceinline__ int drop_layers(const float *wq, const int Lcap, const int S,
+                                           const int n, const float c, const float T)
+{
+    const float dmax = FACT * c * T;
+    int mm = n;
+    float sum = 0.0f;
+    for (int ii = 0; ii < n; ++ii) {
+        if (c < W_B(ii)) {
+            sum = sum + W_D(ii);
+            if (sum > dmax) { mm = ii + 1; break; }
+        }
+    }
+    return mm < 2 ? 2 : mm;
+}
+
+// ================================================================================== K1: phase
+enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3 };
+
+template <int KIND, int G>
+__global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
+{
+    extern __shared__ float w_lds[];
+    constexpr int S = 256 / G;                 // stacks (teams) per workgroup
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int slot = tid / G;
+    const int j = tid % G;                     // lane index inside the team
+    const int tbase = lane - j;                // first lane of my team within the wavefront
+    const unsigned long long tmask =
+        (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << tbase);
+    const int b = blockIdx.x * S + slot;
+    const int Lcap = A.Lmax, B = A.B, P = A.P;
+    float *wq = w_lds + slot;
+    const float *__restrict__ mdl = A.mdl;
+    const size_t fs = (size_t)Lcap * B;
+
+    int n = 0, st = ST_DONE;
+    if (b < B) { n = A.nl[b]; if (n >= 2) st = ST_SCAN; }
+
+    // team-uniform state
+    int k = 0, nsolved = 0, mm_carry = n, mm_frozen = n, sub = 0, passes = 0;
+    float T = 1.0f, b1top = 0.0f;
+    float p0c = 0.0f, p0d = 0.0f;      // "previous point" of lane 0: scan carry or bracket low end
+    float cb = 0.0f, db = 0.0f;        // bracket high end (refine)
+    float croot = 0.0f, r12 = 0.0f;
+    bool first = true;
+    int status = SURFDISP_OK;
+
+    // (re)build the working stack for period k over the first nflat layers only -- the reference
+    // refreshes just the layers inside the previous period's effective half space and leaves the
+    // deeper ones stale (calcul.f:112,133); LDS keeps them across periods exactly like COMMON /d/.
+    auto build = [&](int nflat) {
+        const float lnT = logf(1.0f / T);                      // alog(t_base/t1), calcul.f:122
+        for (int i = j; i < nflat; i += G) {
+            const LayerV v = layer_at(mdl, fs, (size_t)i * B + b, lnT, i == nflat - 1);
+            W_A(i) = v.a; W_B(i) = v.b; W_R(i) = v.rho; W_D(i) = v.d;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    if (st != ST_DONE) {
+        T = A.per[0];
+        // clear the slot (a new process sees zeroed COMMON /d/)
+        for (int i = j; i < Lcap; i += G) { W_A(i) = 0.0f; W_B(i) = 0.0f; W_R(i) = 0.0f; W_D(i) = 0.0f; }
+        build(n);
+        b1top = W_B(0);
+        // first guess, fast_surf.f:157-171
+        const bool water = mdl[F_VS * fs + b] < 0.1f;
+        const int il = water ? 1 : 0;
+        const float b_corr = mdl[F_QS * fs + (size_t)il * B + b] * logf(1.0f / T) / PI_REF;
+        float qq = mdl[F_VS * fs + (size_t)il * B + b];
+        if (KIND == 2) qq = 0.9f * qq;
+        p0c = qq * (1.0f + b_corr);
+        if (water) p0c = 0.5f;
+        first = true;
+    }
+
+    while (__any(st != ST_DONE)) {
+        // ---------------------------------------------------------------- choose the trial point
+        float cj = 1.0f;
+        int mmj = 2, start = 1;
+        bool eval = (st != ST_DONE);
+        if (st == ST_SCAN) {
+            // exact fp32 grid of the reference: c2 = c1 + dc repeatedly (calcul.f:157,161)
+            const int nadd = first ? j : j + 1;
+            cj = p0c;
+#pragma unroll
+            for (int i = 0; i < G; ++i) if (i < nadd) cj = cj + DC;
+            mmj = drop_layers(wq, Lcap, S, n, cj, T);          // idrop=0 before every scan trial
+        } else if (st == ST_REFINE) {
+            cj = p0c + (float)(j + 1) * ((cb - p0c) / (float)(G + 1));
+            mmj = mm_frozen;                                   // frozen as NEVILL sees it
+        } else if (st == ST_ELLIP) {
+            cj = croot; mmj = mm_frozen;
+            start = (G == 1) ? 2 + sub : 2 + j;
+            eval = (G == 1) || (j < 2);
+        }
+        float val = 0.0f;
+        if (eval) {
+            if (KIND == 2) val = delta_rayleigh(wq, Lcap, S, mmj, cj, T, start);
+            else           val = delta_love(wq, Lcap, S, mmj, cj, T);
+        }
+        // ---------------------------------------------------------------- team-level decisions
+        const int lm1 = (lane + 63) & 63;
+        const float sc = __shfl(cj, lm1), sv_ = __shfl(val, lm1);
+        const float pc = (j == 0) ? p0c : sc;
+        const float pd = (j == 0) ? p0d : sv_;
+        const bool searching = (st == ST_SCAN) || (st == ST_REFINE);
+        const bool has_prev = !((st == ST_SCAN) && first && (j == 0));
+        const bool cross = has_prev && (signbit(val) != signbit(pd));
+        bool guard = false;
+        if (st == ST_SCAN && has_prev && !cross)               // calcul.f:165-166
+            guard = (cj < 0.8f * b1top) || !(cj < W_B(mmj - 1) + 0.3f);
+        const bool ev = searching && (cross || guard);
+        const unsigned long long em = __ballot(ev) & tmask;
+        const int fl = em ? (__ffsll((long long)em) - 1) : -1;
+        const int src = (fl < 0) ? tbase : fl;
+        const float e_c = __shfl(cj, src), e_d = __shfl(val, src);
+        const float e_pc = __shfl(pc, src), e_pd = __shfl(pd, src);
+        const int e_mm = __shfl(mmj, src);
+        const int e_cross = __shfl((int)cross, src);
+        const int lastl = tbase + G - 1;
+        const float l_c = __shfl(cj, lastl), l_d = __shfl(val, lastl);
+        const float v0 = __shfl(val, tbase), v1 = __shfl(val, (G > 1) ? tbase + 1 : tbase);
+
+        bool solved = false, failed = false;
+        if (st == ST_SCAN) {
+            ++passes;
+            if (fl >= 0 && e_cross) {                          // bracket found -> refine
+                p0c = e_pc; p0d = e_pd; cb = e_c; db = e_d; mm_frozen = e_mm;
+                st = ST_REFINE;
+            } else if (fl >= 0) {
+                failed = true;                                 // label 250
+            } else {
+                p0c = l_c; p0d = l_d; first = false;
+                if (passes > 100000) failed = true;            // cannot happen: c grows by dc/pass
+            }
+        } else if (st == ST_REFINE) {
+            if (fl >= 0) { p0c = e_pc; p0d = e_pd; cb = e_c; db = e_d; }
+            else         { p0c = l_c;  p0d = l_d; }
+            if (!(cb - p0c > A.wtol)) {
+                // last step: secant through the bracket ends (error ~ w^2 |D''/D'| / 8)
+                float cr = p0c - p0d * (cb - p0c) / (db - p0d);
+                if (!(cr >= p0c)) cr = p0c;
+                if (!(cr <= cb)) cr = cb;
+                croot = cr;
+                if (croot <= W_B(mm_frozen - 1)) {             // calcul.f:191
+                    if (KIND == 2) { st = ST_ELLIP; sub = 0; }
+                    else solved = true;
+                } else failed = true;
+            }
+        } else if (st == ST_ELLIP) {
+            if (G == 1) {
+                if (sub == 0) { r12 = val; sub = 1; }
+                else { r12 = 0.5f * val / r12; solved = true; }
+            } else {
+                r12 = 0.5f * v1 / v0;                          // surfa.f:363
+                solved = true;
+            }
+        }
+        if (solved) {
+            if (j == 0) {
+                A.c[(size_t)b * P + k] = croot;
+                if (KIND == 2) A.ratio[(size_t)k * B + b] = r12;
+            }
+            nsolved = ++k;
+            if (k >= P) { st = ST_DONE; }
+            else {
+                T = A.per[k];
+                mm_carry = mm_frozen;                          // mmax left by the last idrop=0 trial
+                build(mm_carry);
+                b1top = W_B(0);
+                p0c = 0.90f * croot;                           // calcul.f:143
+                p0d = 0.0f; first = true; passes = 0;
+                st = ST_SCAN;
+            }
+        }
+        if (failed) {
+            status = (k == 0) ? SURFDISP_NOROOT : SURFDISP_PARTIAL;
+            st = ST_DONE;
+        }
+    }
+    if (b < B && j == 0) {
+        if (n < 2) status = SURFDISP_BADMODEL;
+        for (int q = nsolved; q < P; ++q) A.c[(size_t)b * P + q] = 0.0f;
+        A.nsolved[b] = nsolved;
+        if (A.status) A.status[b] = status;
+    }
+}
+
+// ================================================================================== K2: group
+// sublayer bookkeeping shared by Rayleigh and Love (surfa.f:781-822 / 412-446): layers are split
+// into ndiv equal sublayers with identical properties, so nothing is materialised -- a layer is
+// visited with a repeat count.
+struct Drop { int hs_layer; int nreg_hs; };
+
+template <int KIND>
+__device__ __forceinline__ Drop drop_group(const float *__restrict__ mdl, size_t fs, int B, int b,
+                                           int n, float lnT, float c, float T, int ndiv, bool water,
+                                           float div)
+{
+    // surfa.f:853-866 (Rayleigh: compares a then b across the cut) / 475-487 (Love: b only).
+    // Cuts can only happen at layer boundaries because sublayers of one layer are identical.
+    const float dmax = FACT * T * c;
+    float sum = 0.0f;
+    Drop r; r.hs_layer = n - 1; r.nreg_hs = 0;
+    for (int jl = 0; jl < n; ++jl) {
+        const LayerV v = layer_at(mdl, fs, (size_t)jl * B + b, lnT, jl == n - 1);
+        if (!(c < v.b)) continue;
+        if (jl == n - 1) break;                                   // ii == mmax: keep the true half space
+        const int nsub = (jl == 0 && water) ? 1 : ndiv;
+        const float dsub = (ndiv > 1 && !(jl == 0 && water)) ? v.d / div : v.d;
+        for (int s = 0; s < nsub; ++s) sum = sum + dsub;
+        if (!(sum > dmax)) continue;
+        const LayerV nx = layer_at(mdl, fs, (size_t)(jl + 1) * B + b, lnT, jl + 1 == n - 1);
+        bool lower, equal;
+        if (KIND == 2) {
+            lower = (nx.a < v.a) || (nx.a == v.a && nx.b < v.b);
+            equal = (nx.a == v.a) && (nx.b == v.b);
+        } else {
+            lower = nx.b < v.b;
+            equal = nx.b == v.b;
+        }
+        if (lower) { r.hs_layer = jl; r.nreg_hs = nsub - 1; break; }   // label 902: mmax = ii
+        if (equal) continue;
+        r.hs_layer = jl + 1; r.nreg_hs = 0; break;                     // label 90009: mmax = ii+1
+    }
+    return r;
+}
+
+// ---- Rayleigh, surfa.f:714-1192 ---------------------------------------------------------------
+struct RCoef { float a12, a13, a21, a24, a31, a34, a42, a43, ddz; };
+
+__device__ __forceinline__ void rk4_step(const RCoef &q, double &ur, double &uz, double &tz, double &tr)
+{
+    // classical RK4 with the reference's fp32 weights (surfa.f:764-771, 955-968)
+    const float w_half = 0.5f * q.ddz, w_one = 1.0f * q.ddz;
+    const float t6 = (1.0f / 6.0f) * q.ddz, t3 = (1.0f / 3.0f) * q.ddz;
+    double d1, d2, d3, d4, e1, e2, e3, e4, s1, s2, s3, s4;
+    // stage 1 (wwt = 0)
+    d1 = q.a31 * uz + q.a34 * tr; d2 = q.a12 * tz + q.a13 * ur;
+    d3 = q.a21 * uz + q.a24 * tr; d4 = q.a42 * tz + q.a43 * ur;
+    e1 = ur + t6 * d1; e2 = uz + t6 * d2; e3 = tz + t6 * d3; e4 = tr + t6 * d4;
+    // stage 2
+    s1 = ur + w_half * d1; s2 = uz + w_half * d2; s3 = tz + w_half * d3; s4 = tr + w_half * d4;
+    d1 = q.a31 * s2 + q.a34 * s4; d2 = q.a12 * s3 + q.a13 * s1;
+    d3 = q.a21 * s2 + q.a24 * s4; d4 = q.a42 * s3 + q.a43 * s1;
+    e1 += t3 * d1; e2 += t3 * d2; e3 += t3 * d3; e4 += t3 * d4;
+    // stage 3
+    s1 = ur + w_half * d1; s2 = uz + w_half * d2; s3 = tz + w_half * d3; s4 = tr + w_half * d4;
+    d1 = q.a31 * s2 + q.a34 * s4; d2 = q.a12 * s3 + q.a13 * s1;
+    d3 = q.a21 * s2 + q.a24 * s4; d4 = q.a42 * s3 + q.a43 * s1;
+    e1 += t3 * d1; e2 += t3 * d2; e3 += t3 * d3; e4 += t3 * d4;
+    // stage 4
+    s1 = ur + w_one * d1; s2 = uz + w_one * d2; s3 = tz + w_one * d3; s4 = tr + w_one * d4;
+    d1 = q.a31 * s2 + q.a34 * s4; d2 = q.a12 * s3 + q.a13 * s1;
+    d3 = q.a21 * s2 + q.a24 * s4; d4 = q.a42 * s3 + q.a43 * s1;
+    ur = e1 + t6 * d1; uz = e2 + t6 * d2; tz = e3 + t6 * d3; tr = e4 + t6 * d4;
+}
+
+struct RInt {                       // energy integrals, fp64 accumulators (reference: fp32 sumi*)
+    double i0, i1, i2;
+};
+
+// integrate both solutions from the half space to the surface.  INTEG: also accumulate the Boole
+// energy integrals of the combined solution (xnorm*y + z)/bb (surfa.f:1087-1129).
+template <bool INTEG>
+__device__ __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t fs, int B, int b,
+                                               int n, float lnT, int ndiv, bool water, float div,
+                                               const Drop dr, float wvno, float wvnosq, float omegsq,
+                                               double y[4], double z[4], bool do_y,
+                                               double xnorm, double bbn, RInt &acc)
+{
+    for (int jl = dr.hs_layer; jl >= 0; --jl) {
+        const int nsub = (jl == 0 && water) ? 1 : ndiv;
+        const int nreg = (jl == dr.hs_layer) ? dr.nreg_hs : nsub;
+        if (nreg <= 0) continue;
+        const LayerV v = layer_at(mdl, fs, (size_t)jl * B + b, lnT, jl == n - 1);
+        if (v.b <= 0.0f) continue;                                   // water: surfa.f:930
+        const float dsub = (ndiv > 1 && !(jl == 0 && water)) ? v.d / div : v.d;
+        const float xmu = v.rho * v.b * v.b;                         // surfa.f:831-832
+        const float xlamb = v.rho * (v.a * v.a - 2.0f * v.b * v.b);
+        RCoef q;
+        q.ddz = -dsub / (4.0f * 1.0f);
+        q.a12 = 1.0f / (xlamb + 2.0f * xmu);
+        q.a13 = wvno * xlamb * q.a12;
+        q.a21 = -omegsq * v.rho;
+        q.a24 = wvno; q.a31 = -wvno;
+        q.a34 = 1.0f / xmu;
+        q.a42 = -q.a13;
+        q.a43 = q.a21 + 4.0f * wvnosq * xmu * (xlamb + xmu) * q.a12;
+        const float dz = dsub / 4.0f;
+        const float l2m = xlamb + 2.0f * xmu;
+        for (int s = 0; s < nreg; ++s) {
+            float f_mr[5], f_mz[5], f_rz[5], f_zr[5];
+            auto knot = [&](int kk) {
+                const float aur = (float)((xnorm * y[0] + z[0]) / bbn);
+                const float auz = (float)((xnorm * y[1] + z[1]) / bbn);
+                const float atz = (float)((xnorm * y[2] + z[2]) / bbn);
+                const float atr = (float)((xnorm * y[3] + z[3]) / bbn);
+                const float durdz = atr / xmu - wvno * auz;
+                const float duzdz = (atz + wvno * xlamb * aur) / l2m;
+                f_mr[kk] = aur * aur; f_mz[kk] = auz * auz;
+                f_rz[kk] = aur * duzdz; f_zr[kk] = auz * durdz;
+            };
+            if (INTEG) knot(4);
+#pragma unroll
+            for (int kk = 3; kk >= 0; --kk) {
+                if (do_y) rk4_step(q, y[0], y[1], y[2], y[3]);
+                rk4_step(q, z[0], z[1], z[2], z[3]);
+                if (INTEG) knot(kk);
+            }
+            if (INTEG) {
+                const float hq = dz / 22.5f;
+#define SD_BOOLE(v) (hq * (7.0f * (v[0] + v[4]) + 32.0f * (v[1] + v[3]) + 12.0f * v[2]))
+                const double dmmr = SD_BOOLE(f_mr), dmmz = SD_BOOLE(f_mz);
+                const double drsz = SD_BOOLE(f_rz), dzsr = SD_BOOLE(f_zr);
+#undef SD_BOOLE
+                acc.i0 += v.rho * (dmmr + dmmz);                        // surfa.f:1126-1128
+                acc.i1 += l2m * dmmr + xmu * dmmz;
+                acc.i2 += xmu * dzsr - xlamb * drsz;
+            }
+        }
+    }
+}
+
+__device__ float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
+                                float T, float c, float ratio)
+{
+    const float lnT = logf(1.0f / T);
+    int ndiv = 5;
+    const int ivre = 99 / (n - 1);                                    // surfa.f:783-784
+    if (ndiv > ivre) ndiv = ivre;
+    if (ndiv < 1) ndiv = 1;
+    const float div = (float)ndiv;
+    const LayerV top = layer_at(mdl, fs, (size_t)b, lnT, false);
+    const bool water = (ndiv > 1) ? (top.b <= 0.1e-10f) : false;      // jj=2 only when splitting
+    const bool wet = !(top.b > 0.0f);
+    const Drop dr = drop_group<2>(mdl, fs, B, b, n, lnT, c, T, ndiv, water, div);
+    const float wvno = 6.2831853072f / (c * T);
+    const float wvnosq = wvno * wvno;
+    const float omega = 6.2831853072f / T;
+    const float omegsq = omega * omega;
+    RInt acc; acc.i0 = 0.0; acc.i1 = 0.0; acc.i2 = 0.0;
+    float tzz = 0.0f;
+    if (wet) {                                                        // surfa.f:879-910
+        const float d1 = top.d;
+        const float xl1 = top.rho * (top.a * top.a - 2.0f * top.b * top.b);
+        const float ra = c / top.a;
+        const float cr1 = ra * ra - 1.0f;
+        const float mag = wvno * sqrtf(fabsf(cr1));
+        if (mag <= 1.0e-35f) {
+            acc.i0 = top.rho * d1;
+        } else {
+            float sin2ra, cosra, rab1, sinra_over;
+            if (cr1 >= 0.0f) {
+                sin2ra = sinf(2.0f * mag * d1) / (4.0f * mag);
+                cosra = cosf(mag * d1);
+                rab1 = mag * mag;
+                sinra_over = sinf(mag * d1) / mag;
+            } else {
+                sin2ra = sinhf(2.0f * mag * d1) / (4.0f * mag);
+                cosra = coshf(mag * d1);
+                rab1 = -(mag * mag);
+                sinra_over = sinhf(mag * d1) / mag;
+            }
+            const float cos2rm = 1.0f / (cosra * cosra);
+            const float fac1 = (0.5f * d1 + sin2ra) * cos2rm;
+            const float fac3 = wvno * (0.5f * d1 - sin2ra) * cos2rm;
+            const float fac2 = wvno * fac3 / rab1;
+            acc.i0 = top.rho * (fac1 + fac2);
+            acc.i1 = xl1 * fac2;
+            acc.i2 = xl1 * fac3;
+            tzz = -top.rho * omegsq * sinra_over / cosra;
+        }
+    }
+    // half-space start vectors, surfa.f:913-926, 986-989
+    const LayerV hsv = layer_at(mdl, fs, (size_t)dr.hs_layer * B + b, lnT, dr.hs_layer == n - 1);
+    const float cova = c / hsv.a, covb = c / hsv.b;
+    const float gam = 2.0f / (covb * covb);
+    const float gamm1 = gam - 1.0f;
+    const float ra = wvno * sqrtf(fabsf(cova * cova - 1.0f));
+    const float rb = wvno * sqrtf(fabsf(covb * covb - 1.0f));
+    const float det = wvnosq - ra * rb;
+    const float h = hsv.rho * omegsq;
+    const float brkt = -gamm1 * wvno + gam * ra * rb / wvno;
+    const double y0[4] = {1.0, 0.0, (double)(-h * brkt / det), (double)(-h * ra / det)};   // ur,uz,tz,tr
+    double z0[4] = {0.0, 1.0, (double)(-h * rb / det), (double)(-h * brkt / det)};
+    double y[4], z[4];
+    // pass 1: surface values of both solutions
+    for (int i = 0; i < 4; ++i) { y[i] = y0[i]; z[i] = z0[i]; }
+    rayleigh_sweep<false>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
+                          y, z, true, 0.0, 1.0, acc);
+    const double yt[4] = {y[0], y[1], y[2], y[3]};
+    double xnorm, bbn;
+    {   // surfa.f:1056-1069
+        double aa = z[0] - ratio * z[1];
+        double bb = ratio * yt[1] - yt[0];
+        if (fabs(bb) < 1.e-10) bb = copysign(1.e-10, bb);
+        xnorm = aa / bb;
+        bb = xnorm * yt[1] + z[1];
+        if (fabs(bb) < 1.e-10) bb = copysign(1.e-10, bb);
+        bbn = bb;
+        const float ampur = (float)((xnorm * yt[0] + z[0]) / bb);
+        const float xtest = fabsf(ampur / ratio - 1.0f);
+        if (xtest >= 0.00001f) {
+            // one refinement: restart solution 2 from the combined vector (surfa.f:990-998)
+            for (int i = 0; i < 4; ++i) { z0[i] = z0[i] + xnorm * y0[i]; z[i] = z0[i]; }
+            rayleigh_sweep<false>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
+                                  y, z, false, 0.0, 1.0, acc);
+            aa = z[0] - ratio * z[1];
+            bb = ratio * yt[1] - yt[0];
+            if (fabs(bb) < 1.e-10) bb = copysign(1.e-10, bb);
+            xnorm = aa / bb;
+            bb = xnorm * yt[1] + z[1];
+            if (fabs(bb) < 1.e-10) bb = copysign(1.e-10, bb);
+            bbn = bb;
+        }
+    }
+    // pass 2: same integration again (bit-identical values), now with the energy integrals
+    for (int i = 0; i < 4; ++i) { y[i] = y0[i]; z[i] = z0[i]; }
+    // half-space analytic terms use the combined vector at the top of the half space
+    float aur = (float)((xnorm * y0[0] + z0[0]) / bbn);
+    float auz = (float)((xnorm * y0[1] + z0[1]) / bbn);
+    const bool any_solid = (dr.hs_layer > (wet ? 1 : 0)) || (dr.nreg_hs > 0);
+    if (wet && !any_solid) { aur = ratio; auz = 1.0f; }              // label 77777, surfa.f:1140-1144
+    (void)tzz;
+    rayleigh_sweep<true>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
+                         y, z, true, xnorm, bbn, acc);
+    {   // label 7002, surfa.f:1145-1186
+        const float xmu = hsv.rho * hsv.b * hsv.b;
+        const float xlamb = hsv.rho * (hsv.a * hsv.a - 2.0f * hsv.b * hsv.b);
+        const float ap = -hsv.rho * (wvno * aur + rb * auz) / det;
+        const float bp = -hsv.rho * (-ra * aur / wvno - auz) / det;
+        const float a1 = -wvno * ap / hsv.rho;
+        const float a2 = -wvno * rb * bp / hsv.rho;
+        const float a3 = ra * ap / hsv.rho;
+        const float a4 = wvnosq * bp / hsv.rho;
+        if (rb == 0.0f) return hsv.b;                                 // label 7006
+        const double dmmr = a1 * a1 / (2.0f * ra) + 2.0f * a1 * a2 / (ra + rb) + a2 * a2 / (2.0f * rb);
+        const double dmmz = a3 * a3 / (2.0f * ra) + 2.0f * a3 * a4 / (ra + rb) + a4 * a4 / (2.0f * rb);
+        const double drsz = -a1 * a3 / 2.0f - (a1 * a4 * rb + a2 * a3 * ra) / (ra + rb) - a2 * a4 / 2.0f;
+        const double dzsr = -a1 * a3 / 2.0f - (a1 * a4 * ra + a2 * a3 * rb) / (ra + rb) - a2 * a4 / 2.0f;
+        acc.i0 += hsv.rho * (dmmr + dmmz);
+        acc.i1 += (xlamb + 2.0f * xmu) * dmmr + xmu * dmmz;
+        acc.i2 += xmu * dzsr - xlamb * drsz;
+    }
+    const float s0 = (float)acc.i0, s1 = (float)acc.i1, s2 = (float)acc.i2;
+    return (wvno * s1 + s2) / (omega * s0);                           // surfa.f:1186
+}
+
+// ---- Love, surfa.f:374-606 (all fp32, as the reference) --------------------------------------
+__device__ float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
+                            float T, float c)
+{
+    const float lnT = logf(1.0f / T);
+    int ndiv = 5;
+    const int ivre = 999 / (n - 1);                                   // surfa.f:414-415
+    if (ndiv > ivre) ndiv = ivre;
+    if (ndiv < 1) ndiv = 1;
+    const float div = (float)ndiv;
+    const LayerV top = layer_at(mdl, fs, (size_t)b, lnT, false);
+    const bool water = (ndiv > 1) ? (top.b <= 0.1e-10f) : false;
+    const Drop dr = drop_group<1>(mdl, fs, B, b, n, lnT, c, T, ndiv, water, div);
+    const float wvno = 6.2831853f / (c * T);
+    const LayerV hsv = layer_at(mdl, fs, (size_t)dr.hs_layer * B + b, lnT, dr.hs_layer == n - 1);
+    float ut0 = 1.0f;
+    for (int attempt = 0; attempt < 16; ++attempt) {
+        float ut = ut0;
+        const float covb = c / hsv.b;
+        const float hh = hsv.rho * hsv.b * hsv.b;
+        const float rbh = wvno * sqrtf(fabsf(covb * covb - 1.0f));
+        float tq = -hh * rbh * ut0;
+        const float dm0 = (rbh == 0.0f) ? 1.0e25f : 0.5f / rbh;
+        float sumi0 = hsv.rho * dm0;
+        float sumi1 = hh * dm0;
+        bool overflow = false;
+        for (int jl = dr.hs_layer; jl >= 0 && !overflow; --jl) {
+            const int nsub = (jl == 0 && water) ? 1 : ndiv;
+            const int nreg = (jl == dr.hs_layer) ? dr.nreg_hs : nsub;
+            if (nreg <= 0) continue;
+            const LayerV v = layer_at(mdl, fs, (size_t)jl * B + b, lnT, jl == n - 1);
+            if (v.b == 0.0f) {                                        // surfa.f:524 (still tests |ut|)
+                if (fabsf(ut) > 1.0e10f) overflow = true;
+                continue;
+            }
+            const float dsub = (ndiv > 1 && !(jl == 0 && water)) ? v.d / div : v.d;
+            const float cv = c / v.b;
+            const float rb = wvno * sqrtf(fabsf(cv * cv - 1.0f));
+            const float h = v.rho * v.b * v.b;
+            const float dz = dsub / 4.0f;
+            // the four quarter-step propagators are the same for every sublayer of this layer
+            float yk[4], zk[4], ck[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float xkk = (float)(kk + 1);
+                const float q = rb * dz * xkk;
+                if (c < v.b) {
+                    const float ep = expf(q), emq = 1.0f / ep;
+                    yk[kk] = (ep - emq) / (2.0f * rb);
+                    zk[kk] = rb * rb * yk[kk];
+                    ck[kk] = (ep + emq) / 2.0f;
+                } else if (c == v.b) {
+                    yk[kk] = dz * xkk; zk[kk] = 0.0f; ck[kk] = 1.0f;
+                } else {
+                    float sn, cs; sincosf(q, &sn, &cs);
+                    yk[kk] = sn / rb; zk[kk] = -rb * sn; ck[kk] = cs;
+                }
+            }
+            for (int s = 0; s < nreg; ++s) {
+                if (fabsf(ut) > 1.0e10f) { overflow = true; break; } // surfa.f:519-522
+                float dmm[5];
+                dmm[0] = ut * ut;
+                float eut = ut, ett = tq;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    eut = ck[kk] * ut - yk[kk] * tq / h;
+                    ett = -h * zk[kk] * ut + ck[kk] * tq;
+                    dmm[kk + 1] = eut * eut;
+                }
+                ut = eut; tq = ett;
+                const float dm = (dz / 22.5f) * (7.0f * (dmm[0] + dmm[4]) + 32.0f * (dmm[1] + dmm[3]) + 12.0f * dmm[2]);
+                sumi0 = sumi0 + v.rho * dm;
+                sumi1 = sumi1 + h * dm;
+            }
+        }
+        if (overflow) { ut0 = ut0 / 1.0e5f; continue; }
+        sumi0 = sumi0 / (ut * ut);
+        sumi1 = sumi1 / (ut * ut);
+        return sumi1 / (c * sumi0);                                   // surfa.f:606
+    }
+    return 0.0f;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void surfdisp_group_kernel(GroupArgs A)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int B = A.B, P = A.P;
+    if (idx >= (size_t)B * P) return;
+    const int b = (int)(idx % B), k = (int)(idx / B);       // a wavefront = 64 stacks, one period
+    const size_t o = (size_t)b * P + k;
+    const int n = A.nl[b];
+    if (n < 2 || k >= A.nsolved[b]) { A.u[o] = 0.0f; return; }
+    const size_t fs = (size_t)A.Lmax * B;
+    const float T = A.per[k];
+    const float c = A.c[o];
+    float ugr;
+    if (KIND == 2) ugr = group_rayleigh(A.mdl, fs, B, b, n, T, c, A.ratio[(size_t)k * B + b]);
+    else           ugr = group_love(A.mdl, fs, B, b, n, T, c);
+    A.u[o] = ugr;
+}
+
+}  // namespace sd
+
+// ======================================================================================= launch
+namespace {
+
+template <int KIND, int G>
+hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
+{
+    constexpr int S = 256 / G;
+    const size_t lds = (size_t)4 * a.Lmax * S * sizeof(float);
+    auto kern = sd::surfdisp_phase_kernel<KIND, G>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int grid = (a.B + S - 1) / S;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int KIND>
+hipError_t launch_phase_k(hipStream_t s, const sd::PhaseArgs &a, int G)
+{
+    switch (G) {
+        case 1:  return launch_phase_g<KIND, 1>(s, a);
+        case 2:  return launch_phase_g<KIND, 2>(s, a);
+        case 4:  return launch_phase_g<KIND, 4>(s, a);
+        case 8:  return launch_phase_g<KIND, 8>(s, a);
+        case 16: return launch_phase_g<KIND, 16>(s, a);
+        case 32: return launch_phase_g<KIND, 32>(s, a);
+        case 64: return launch_phase_g<KIND, 64>(s, a);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+namespace sd {
+
+size_t phase_lds_bytes(int Lmax, int G) { return (size_t)4 * Lmax * (256 / G) * sizeof(float); }
+
+hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a)
+{
+    const int grid = (a.B + 255) / 256;
+    if (kind == 2) hipLaunchKernelGGL(surfdisp_prep_kernel<2>, dim3(grid), dim3(256), 0, s, a);
+    else           hipLaunchKernelGGL(surfdisp_prep_kernel<1>, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_phase(hipStream_t s, int kind, int G, const PhaseArgs &a)
+{
+    return kind == 2 ? launch_phase_k<2>(s, a, G) : launch_phase_k<1>(s, a, G);
+}
+
+hipError_t launch_group(hipStream_t s, int kind, const GroupArgs &a)
+{
+    const size_t total = (size_t)a.B * a.P;
+    const int grid = (int)((total + 255) / 256);
+    if (kind == 2) hipLaunchKernelGGL(surfdisp_group_kernel<2>, dim3(grid), dim3(256), 0, s, a);
+    else           hipLaunchKernelGGL(surfdisp_group_kernel<1>, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace sd

@@ -1,0 +1,117 @@
+"""Host side of the forward-call boundary (reference layer L2, models.py:11-33).
+
+* ``_calForward`` mirrors ``pySurfInv.models._calForward`` (same name, arguments,
+  return value and failure convention) on top of the HIP library.
+* ``forward_batch`` / ``forward_batch_torch`` are the batched entry points the
+  reference does not have: B layer stacks -> c[B,P], U[B,P] in one launch.
+
+numpy / torch are plumbing only; the arithmetic is in libsurfdisp_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from . import fast_surf as _fast_surf_mod
+
+
+def _calForward(inProfile, wavetype="Ray", periods=(5, 10, 20, 40, 60, 80), debug=False):
+    """models.py:11-33: profile rows (h, Vs, Vp, rho, qs, qp) -> cR[:nper] or None."""
+    if wavetype == "Ray":
+        ilvry = 2
+    elif wavetype == "Love":
+        ilvry = 1
+    else:
+        raise ValueError("Wrong surface wave type: %s!" % wavetype)
+    inProfile = np.asarray(inProfile)
+    ind = np.where(inProfile[0] > 1e-3)[0]                 # models.py:20
+    h, Vs, Vp, rho, qs, qp = inProfile[:, ind]
+    qsinv = 1.0 / qs
+    nper = len(periods)
+    per = np.zeros(200, dtype=np.float64)
+    per[:nper] = periods[:]
+    nlay = h.size
+    (ur0, ul0, cr0, cl0) = _fast_surf_mod.fast_surf(nlay, ilvry, Vp, Vs, rho, h, qsinv, per, nper)
+    if np.any(cr0[:nper] < 0.01):                          # models.py:29 (yes: cr0 for Love too)
+        if debug:
+            print(cr0[:nper])
+        return None
+    return cr0[:nper]
+
+
+def forward_batch(model, periods, kind=2, nlay=None, device=0):
+    """model float32 [B,5,L] rows (vp, vs, rho, h, qsinv) -> (c[B,P], u[B,P], status[B]).
+
+    Host buffers in, host buffers out (C ABI surfdisp_forward_batch)."""
+    L = _lib.lib()
+    model = np.ascontiguousarray(model, dtype=np.float32)
+    if model.ndim != 3 or model.shape[1] != 5:
+        raise ValueError("model must be [B, 5, L]")
+    B, _, Lmax = model.shape
+    per = np.ascontiguousarray(periods, dtype=np.float32).ravel()
+    P = per.size
+    c = np.zeros((B, P), np.float32); u = np.zeros((B, P), np.float32)
+    status = np.zeros(B, np.int32)
+    fp = lambda x: x.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    ip = lambda x: x.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    nl = None
+    if nlay is not None:
+        nlay = np.ascontiguousarray(nlay, dtype=np.int32)
+        if nlay.size != B:
+            raise ValueError("nlay must have B entries")
+        nl = ip(nlay)
+    _lib.check(L.surfdisp_forward_batch(int(device), B, Lmax, nl, fp(model), P, fp(per), int(kind),
+                                        fp(c), fp(u), ip(status)))
+    return c, u, status
+
+
+class BatchPlan:
+    """Device-resident, stream-ordered batched solve on torch tensors.
+
+    Owns the workspace and output tensors for a fixed (B, L, P); ``run`` launches the
+    three kernels on torch's current stream without allocating or synchronising, so it
+    can be captured in a HIP graph."""
+
+    def __init__(self, B, L, P, device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.B, self.L, self.P = int(B), int(L), int(P)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.SurfdispError("BatchPlan needs a HIP device tensor (no CPU fallback)")
+        lib = _lib.lib()
+        self.ws_bytes = int(lib.surfdisp_workspace_bytes(self.B, self.L, self.P))
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
+        self.c = torch.zeros(self.B, self.P, dtype=torch.float32, device=self.device)
+        self.u = torch.zeros(self.B, self.P, dtype=torch.float32, device=self.device)
+        self.status = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+
+    def run(self, model, periods, kind=2, nlay=None):
+        torch = self.torch
+        for t, shape in ((model, (self.B, 5, self.L)), (periods, (self.P,))):
+            if (t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shape
+                    or t.device != self.device):
+                raise ValueError(f"expected contiguous float32 {shape} on {self.device}")
+        if nlay is not None and (nlay.dtype != torch.int32 or nlay.numel() != self.B
+                                 or nlay.device != self.device):
+            raise ValueError("nlay must be int32 [B] on the same device")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().surfdisp_forward_batch_device(
+                ctypes.c_void_p(stream), self.B, self.L,
+                ctypes.c_void_p(nlay.data_ptr() if nlay is not None else 0),
+                ctypes.c_void_p(model.data_ptr()), self.P, ctypes.c_void_p(periods.data_ptr()),
+                int(kind), ctypes.c_void_p(self.c.data_ptr()), ctypes.c_void_p(self.u.data_ptr()),
+                ctypes.c_void_p(self.status.data_ptr()), ctypes.c_void_p(self.workspace.data_ptr()),
+                self.ws_bytes)
+        _lib.check(rc)
+        return self.c, self.u, self.status
+
+
+def forward_batch_torch(model, periods, kind=2, nlay=None):
+    """One-shot torch entry: allocates a BatchPlan and runs it (outputs stay on the device)."""
+    B, _, L = model.shape
+    plan = BatchPlan(B, L, periods.numel(), device=model.device)
+    return plan.run(model, periods, kind=kind, nlay=nlay)

@@ -1,0 +1,80 @@
+"""CPU-only checks of the host logic and the C-ABI library (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from pysurfinv_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "surfdisp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(surfdisp_[a-z_]+|fast_surf_)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert L.surfdisp_abi_version() == 1
+    assert L.surfdisp_kernel_name(1) == b"surfdisp_phase_kernel"
+
+
+def test_workspace_and_team_heuristics():
+    from pysurfinv_amd import _lib
+    L = _lib.lib()
+    assert L.surfdisp_workspace_bytes(65536, 10, 20) >= 65536 * (10 * 10 + 20) * 4
+    assert L.surfdisp_workspace_bytes(0, 10, 20) == 0
+    L.surfdisp_set_team(0)
+    os.environ.pop("SURFDISP_TEAM", None)
+    assert L.surfdisp_get_team(1, 10) == 64              # one stack: a whole wavefront
+    assert L.surfdisp_get_team(1 << 20, 10) == 1         # huge batch: a lane per stack
+    g = L.surfdisp_get_team(1 << 20, 200)                # LDS bound forces wider teams
+    assert g >= 8 and 4 * 200 * (256 // g) * 4 <= 80 * 1024
+    assert L.surfdisp_set_team(3) == _lib.ERR_INVALID
+    assert L.surfdisp_set_team(16) == 0 and L.surfdisp_get_team(5, 5) == 16
+    L.surfdisp_set_team(0)
+
+
+def test_argument_errors_without_touching_a_gpu():
+    from pysurfinv_amd import _lib, forward
+    L = _lib.lib()
+    with pytest.raises(ValueError):
+        forward.forward_batch(np.zeros((4, 4, 10), np.float32), [10.0])
+    with pytest.raises(_lib.SurfdispError):
+        forward.forward_batch(np.ones((4, 5, 10), np.float32), np.arange(1, 300.0))   # P > 200
+    with pytest.raises(_lib.SurfdispError):
+        forward.forward_batch(np.ones((4, 5, 10), np.float32), [10.0], kind=3)
+    assert b"invalid" in L.surfdisp_last_error()
+
+
+def test_no_cpu_fallback_when_no_device():
+    """On a box without a GPU the product path must fail loudly, not compute on the CPU."""
+    from pysurfinv_amd import _lib, forward, synth
+    if _lib.lib().surfdisp_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(_lib.SurfdispError):
+        forward.forward_batch(synth.synth_models(2, 5), synth.default_periods(4))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pysurfinv_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.replace("no CPU fallback", ""), os.path.join(dp, f)
+
+
+def test_synth_generator_is_deterministic_and_shaped():
+    from pysurfinv_amd import synth
+    a = synth.synth_models(8, 10, seed=0); b = synth.synth_models(8, 10, seed=0)
+    assert a.shape == (8, 5, 10) and a.dtype == np.float32 and np.array_equal(a, b)
+    assert (np.diff(a[:, 1], axis=1) >= 0).all()
+    w = synth.water_models(3)
+    assert (w[:, 1, 0] == 0).all()
