@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- layered-model dispersion forward solves/sec (20 periods) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): batch of 65 536 MCMC-perturbed 10-layer stacks per GPU,
+Rayleigh phase + group velocity at 20 periods, synthetic inputs of SURVEY.md section 8(d).
+A "step" = one pass of the hot path (prep + root-search + group-velocity kernels) over one
+batch that is already resident in HBM.  The path shards over independent stacks: each rank
+owns its own batch (weak scaling), no data-path collective; the only communication is the
+barrier + MAX-reduce of the timing.
+
+Prints ONE JSON line on rank 0 with metric/value plus:
+  roofline     - dominant kernel (root search), algorithmic bytes per launch / HIP-event duration
+  cpu_baseline - the reference Fortran (oracle/_ref, flang -O2) on one host core, bounded sample;
+                 the OpenMP C port on all cores is reported beside it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU = 65536
+NLAY = 10
+NPER = 20
+KIND = 2                      # Rayleigh
+ALG_BYTES_PER_SOLVE = 20 * NLAY + 8 * NPER    # 5 fp32 arrays in, (c, U) out = 360 B
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(per):
+    """Bounded CPU sample on the host cores (rank 0, N=1 only).  Checker code, timed - never the product."""
+    from pysurfinv_amd import synth
+    from oracle import cport, refso
+    ncores = os.cpu_count() or 1
+    out = {}
+    sample = synth.synth_models(8192, NLAY, seed=0)
+    if refso.available():
+        n = 6144                                     # ~9 s at ~700 solves/s/core
+        t0 = time.perf_counter()
+        refso.forward_batch(sample[:n, 0], sample[:n, 1], sample[:n, 2], sample[:n, 3], sample[:n, 4], per, KIND)
+        dt = time.perf_counter() - t0
+        out = {"value": n / dt, "unit": "solves/s", "cores": 1, "kind": "reference",
+               "sample": f"first {n} of the bench batch (B=65536 L=10 P=20 Rayleigh c+U), "
+                         "unmodified fast_surf Fortran built by oracle/build_ref.sh (flang -O2), "
+                         "non-reentrant so one core"}
+    # the reentrant C port, all host cores
+    cport.forward_batch(sample[:256], per, KIND, nthreads=ncores)
+    t0 = time.perf_counter()
+    cport.forward_batch(sample, per, KIND, nthreads=ncores)
+    dtp = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cport.forward_batch(sample[:2048], per, KIND, nthreads=1)
+    dt1 = time.perf_counter() - t0
+    port = {"value": sample.shape[0] / dtp, "unit": "solves/s", "cores": ncores, "kind": "port",
+            "sample": "8192 stacks of the bench batch, oracle/surfdisp_oracle.c with OpenMP",
+            "one_core_value": 2048 / dt1}
+    if not out:
+        out = dict(port)
+    else:
+        out["port_all_cores"] = port
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from pysurfinv_amd import _lib, forward, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device(f"cuda:{local_rank}"))   # nccl == RCCL on ROCm
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    if _lib.lib().surfdisp_device_count() < 1:
+        raise SystemExit("no HIP device: the product path has no CPU fallback")
+
+    per_np = synth.default_periods(NPER)
+    model = torch.from_numpy(synth.synth_models(B_PER_GPU, NLAY, seed=rank)).to(dev)
+    per = torch.from_numpy(per_np).to(dev)
+    plan = forward.BatchPlan(B_PER_GPU, NLAY, NPER, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        plan.run(model, per, kind=KIND)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.run(model, per, kind=KIND)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # every stack of every rank must have been solved (work was not skipped)
+    n_ok = int((plan.status == 0).sum().item())
+    ok = torch.tensor([n_ok], dtype=torch.int64, device=dev)
+    if dist is not None:
+        dist.all_reduce(ok, op=dist.ReduceOp.SUM)
+
+    # live per-kernel durations (HIP events on the launch stream), outside the timed region
+    kms = np.zeros(3)
+    nrep = 5
+    for _ in range(nrep):
+        *_, ms = plan.run_timed(model, per, kind=KIND)
+        kms += np.array(ms)
+    kms /= nrep
+
+    if rank == 0:
+        total_solves = world * B_PER_GPU * args.steps
+        value = total_solves / elapsed
+        phase_s = kms[1] * 1e-3
+        achieved = ALG_BYTES_PER_SOLVE * B_PER_GPU / phase_s / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("phase_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "layered-model dispersion forward solves/sec (20 periods)",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (root search, Love group velocity) + f64 (Rayleigh eigenfunction state)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 65536 MCMC-perturbed 10-layer stacks per GPU, "
+                                   "Rayleigh phase+group velocity at 20 periods",
+                       "stacks_per_gpu": B_PER_GPU, "layers": NLAY, "periods": NPER,
+                       "wave": "Rayleigh c+U", "team_lanes": int(_lib.lib().surfdisp_get_team(B_PER_GPU, NLAY)),
+                       "sharding": f"independent stacks, {world} rank(s), no data-path collective"},
+            "solved_fraction": float(ok.item()) / (world * B_PER_GPU),
+            "kernel_ms": {"prep": kms[0], "phase": kms[1], "group": kms[2]},
+            "roofline": {"bound": "hbm", "kernel": "surfdisp_phase_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic,
+                         "note": "algorithmic bytes = 360 B/solve x 65536 solves per launch; the path is "
+                                 "VALU/transcendental-bound, not HBM-bound (SURVEY.md 8(d))"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(per_np)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,6 +87,14 @@ int surfdisp_forward_batch_device(void *stream, int B, int Lmax, const int *nlay
                                   float *c, float *u, int *status,
                                   void *workspace, size_t workspace_bytes);
 
+/* ---- (4) measurement variant of (3): identical launches bracketed by HIP events recorded on
+ *          `stream`; blocks until done; kernel_ms[3] = durations of the prep, phase (root search)
+ *          and group-velocity kernels in milliseconds.  Used by bench.py's roofline figures. */
+int surfdisp_forward_batch_device_timed(void *stream, int B, int Lmax, const int *nlay,
+                                        const float *model, int P, const float *per, int kind,
+                                        float *c, float *u, int *status,
+                                        void *workspace, size_t workspace_bytes, float *kernel_ms);
+
 /* ---- tuning / introspection ------------------------------------------------------------- */
 /* lanes of one wavefront that cooperate on one stack's root search (1,2,4,...,64); 0 = choose
  * from (B, Lmax).  Also settable through the environment variable SURFDISP_TEAM. */

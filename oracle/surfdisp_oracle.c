@@ -772,7 +772,7 @@ static int forward_ctx(ctx_t *s, int nlay, int kind,
                        const float *vp, const float *vs, const float *rho,
                        const float *h, const float *qsinv,
                        const float *per, int nper,
-                       float *c_out, float *u_out, int *nsolved, long *n_delta_out)
+                       float *c_out, float *u_out, int *nsolved, long *n_delta_out, float *ratio_out)
 {
     if (nsolved) *nsolved = 0;
     if (nlay < 2 || nlay > SURFDISP_NLAY_MAX || nper < 1 || nper > SURFDISP_NPER_MAX ||
@@ -854,6 +854,7 @@ static int forward_ctx(ctx_t *s, int nlay, int kind,
             float ugr = (kind == 2) ? reigen(s, t, c[lip], ratio[lip]) : leigen(s, t, c[lip]);
             u_out[lip] = ugr;
             c_out[lip] = c[lip];
+            if (ratio_out) ratio_out[lip] = ratio[lip];
         }
         if (nsolved) *nsolved = imax;
     }
@@ -870,7 +871,22 @@ int surfdisp_oracle_forward(int nlay, int kind,
     ctx_t *s = (ctx_t *)malloc(sizeof(ctx_t));
     if (!s) return SURFDISP_ORACLE_EINVAL;
     int st = forward_ctx(s, nlay, kind, vp, vs, rho, h, qsinv, per, nper, c_out, u_out,
-                         nsolved, n_delta_out);
+                         nsolved, n_delta_out, NULL);
+    free(s);
+    return st;
+}
+
+/* debug variant: also returns the Rayleigh ellipticity ratio(k) of calcul.f:195 */
+int surfdisp_oracle_forward_dbg(int nlay, int kind,
+                                const float *vp, const float *vs, const float *rho,
+                                const float *h, const float *qsinv,
+                                const float *per, int nper,
+                                float *c_out, float *u_out, float *ratio_out)
+{
+    ctx_t *s = (ctx_t *)malloc(sizeof(ctx_t));
+    if (!s) return SURFDISP_ORACLE_EINVAL;
+    int st = forward_ctx(s, nlay, kind, vp, vs, rho, h, qsinv, per, nper, c_out, u_out,
+                         NULL, NULL, ratio_out);
     free(s);
     return st;
 }
@@ -915,7 +931,7 @@ int surfdisp_oracle_forward_batch(int B, int Lmax, const int *nlay, const float 
             int ns = 0;
             int st = s ? forward_ctx(s, n, kind, m, m + Lmax, m + 2 * Lmax, m + 3 * Lmax,
                                      m + 4 * Lmax, per, P, c + (size_t)i * P, u + (size_t)i * P,
-                                     &ns, NULL)
+                                     &ns, NULL, NULL)
                        : SURFDISP_ORACLE_EINVAL;
             if (status) status[i] = st;
             if (st != SURFDISP_ORACLE_OK) bad++;

@@ -19,7 +19,7 @@ NPER_MAX, NLAY_MAX = 200, 200
 # every symbol include/surfdisp.h declares
 EXPORTS = (
     "fast_surf_", "surfdisp_forward_batch", "surfdisp_workspace_bytes",
-    "surfdisp_forward_batch_device", "surfdisp_set_team", "surfdisp_get_team",
+    "surfdisp_forward_batch_device", "surfdisp_forward_batch_device_timed", "surfdisp_set_team", "surfdisp_get_team",
     "surfdisp_device_count", "surfdisp_abi_version", "surfdisp_last_error",
     "surfdisp_kernel_name",
 )
@@ -56,6 +56,10 @@ def lib() -> ctypes.CDLL:
     L.surfdisp_forward_batch_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp,
                                                 ctypes.c_int, vp, ctypes.c_int, vp, vp, vp,
                                                 vp, ctypes.c_size_t]
+    L.surfdisp_forward_batch_device_timed.restype = ctypes.c_int
+    L.surfdisp_forward_batch_device_timed.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp,
+                                                      ctypes.c_int, vp, ctypes.c_int, vp, vp, vp,
+                                                      vp, ctypes.c_size_t, fp]
     L.surfdisp_set_team.restype = ctypes.c_int
     L.surfdisp_set_team.argtypes = [ctypes.c_int]
     L.surfdisp_get_team.restype = ctypes.c_int

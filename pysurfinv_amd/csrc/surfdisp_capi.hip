@@ -11,6 +11,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 int g_team_override = 0;
+double *g_dbg = nullptr;    // developer hook, see surfdisp_debug_buffer
 
 void set_err(const char *fmt, const char *a = "", const char *b = "")
 {
@@ -117,16 +118,20 @@ int surfdisp_set_team(int lanes)
 
 int surfdisp_get_team(int B, int Lmax) { return pick_team(B, Lmax); }
 
+// developer hook (not in include/surfdisp.h): device buffer of B*P*16 doubles receiving
+// group-velocity intermediates of the next launches; nullptr switches it off.
+void surfdisp_debug_buffer(double *dev) { g_dbg = dev; }
+
 size_t surfdisp_workspace_bytes(int B, int Lmax, int P)
 {
     if (B < 1 || Lmax < 2 || P < 1) return 0;
     return carve(nullptr, B, Lmax, P).total;
 }
 
-int surfdisp_forward_batch_device(void *stream, int B, int Lmax, const int *nlay,
-                                  const float *model, int P, const float *per, int kind,
-                                  float *c, float *u, int *status,
-                                  void *workspace, size_t workspace_bytes)
+static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
+                               const float *model, int P, const float *per, int kind,
+                               float *c, float *u, int *status,
+                               void *workspace, size_t workspace_bytes, hipEvent_t *ev)
 {
     int rc = check_args(B, Lmax, P, kind, model, per, c, u);
     if (rc) return rc;
@@ -139,14 +144,53 @@ int surfdisp_forward_batch_device(void *stream, int B, int Lmax, const int *nlay
     const int G = pick_team(B, Lmax);
 
     sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl};
+    if (ev) SD_HIP(hipEventRecord(ev[0], s));
     SD_HIP(sd::launch_prep(s, kind, pa));
-    float wtol = 3.2e-4f;
+    if (ev) SD_HIP(hipEventRecord(ev[1], s));
+    float wtol = 1.2e-3f, atol = 1.0e-6f;
     if (const char *e = getenv("SURFDISP_WTOL")) wtol = (float)atof(e);
-    sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, c, w.ratio, w.nsolved, status, wtol};
+    if (const char *e = getenv("SURFDISP_ATOL")) atol = (float)atof(e);
+    sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, c, w.ratio, w.nsolved, status, wtol, atol};
     SD_HIP(sd::launch_phase(s, kind, G, ph));
-    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, c, w.ratio, w.nsolved, u};
+    if (ev) SD_HIP(hipEventRecord(ev[2], s));
+    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, c, w.ratio, w.nsolved, u, g_dbg};
     SD_HIP(sd::launch_group(s, kind, ga));
+    if (ev) SD_HIP(hipEventRecord(ev[3], s));
     return SURFDISP_SUCCESS;
+}
+
+int surfdisp_forward_batch_device(void *stream, int B, int Lmax, const int *nlay,
+                                  const float *model, int P, const float *per, int kind,
+                                  float *c, float *u, int *status,
+                                  void *workspace, size_t workspace_bytes)
+{
+    return forward_device_impl(stream, B, Lmax, nlay, model, P, per, kind, c, u, status,
+                               workspace, workspace_bytes, nullptr);
+}
+
+// Measurement variant: same launches, bracketed by HIP events recorded ON THE LAUNCH STREAM;
+// waits for completion and returns the three kernel durations in milliseconds
+// (kernel_ms[0..2] = prep, phase, group).  Not capturable in a graph (it synchronises).
+int surfdisp_forward_batch_device_timed(void *stream, int B, int Lmax, const int *nlay,
+                                        const float *model, int P, const float *per, int kind,
+                                        float *c, float *u, int *status,
+                                        void *workspace, size_t workspace_bytes, float *kernel_ms)
+{
+    if (!kernel_ms) { set_err("kernel_ms is NULL"); return SURFDISP_ERR_INVALID; }
+    hipEvent_t ev[4];
+    for (int i = 0; i < 4; ++i) SD_HIP(hipEventCreate(&ev[i]));
+    int rc = forward_device_impl(stream, B, Lmax, nlay, model, P, per, kind, c, u, status,
+                                 workspace, workspace_bytes, ev);
+    if (rc == SURFDISP_SUCCESS) {
+        hipError_t e = hipEventSynchronize(ev[3]);
+        if (e != hipSuccess) { set_err("hipEventSynchronize failed: %s", hipGetErrorString(e)); rc = SURFDISP_ERR_HIP; }
+        for (int i = 0; i < 3 && rc == SURFDISP_SUCCESS; ++i)
+            if (hipEventElapsedTime(&kernel_ms[i], ev[i], ev[i + 1]) != hipSuccess) {
+                set_err("hipEventElapsedTime failed"); rc = SURFDISP_ERR_HIP;
+            }
+    }
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
 }
 
 int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const float *model,

@@ -24,7 +24,8 @@ struct PhaseArgs {
     float *ratio;         // [P][B] ellipticity (Rayleigh), input of the group-velocity kernel
     int *nsolved;         // [B]
     int *status;          // [B] or nullptr
-    float wtol;           // bracket width below which the root is read off by a secant step
+    float wtol;           // bracket width below which the root may be read off by interpolation
+    float atol;           // ... provided secant and 3-point estimates agree to this (km/s)
 };
 
 struct GroupArgs {
@@ -36,6 +37,7 @@ struct GroupArgs {
     const float *ratio;
     const int *nsolved;
     float *u;             // [B][P]
+    double *dbg;          // nullptr, or [B][P][16] intermediate values (developer builds)
 };
 
 size_t phase_lds_bytes(int Lmax, int G);

@@ -26,37 +26,45 @@
 #include <stdint.h>
 #include "surfdisp_internal.h"
 
+#define SD_HD __host__ __device__
+
 namespace sd {
 
 // ---- reference constants ---------------------------------------------------------------------
-__device__ constexpr float R0      = 6371.0f;       // flat1.f:21
-__device__ constexpr float PI_REF  = 3.1415927f;    // calcul.f:32, fast_surf.f:77
-__device__ constexpr float DC      = 0.01f;         // init.f:25
-__device__ constexpr float FACT    = 4.0f;          // init.f:25
-__device__ constexpr float ACCUR   = 1.e-8f;        // surfa.f:191-192
+constexpr float R0      = 6371.0f;       // flat1.f:21
+constexpr float PI_REF  = 3.1415927f;    // calcul.f:32, fast_surf.f:77
+constexpr float DC      = 0.01f;         // init.f:25
+constexpr float FACT    = 4.0f;          // init.f:25
+constexpr float ACCUR   = 1.e-8f;        // surfa.f:191-192
 
 // SoA field ids of mdl[NF][Lmax][B]
 enum { F_VP = 0, F_VS, F_RHO, F_H, F_QS, F_DIF, F_QQQ, F_DFL, F_HSF, F_HSR, NF = 10 };
 
-__device__ __forceinline__ float pwr_of(int kind) { return kind == 1 ? 5.0f : 2.2750f; }  // flat1.f:27-28
+SD_HD __forceinline__ bool fin(float x) { return fabsf(x) <= 3.402823466e38f; }   // finite, host+device
+SD_HD __forceinline__ float pwr_of(int kind) { return kind == 1 ? 5.0f : 2.2750f; }  // flat1.f:27-28
 
 // =================================================================================== K0: prep
 // One lane per stack.  Flattening factors depend only on the radii, i.e. on the thickness prefix
 // sums (flat1.f:33-37), not on the period or on how many layers are flattened:
 //   regular layer i : dif_i, qqq_i (flat1.f:44-56), new thickness z1(i+1)-z1(i) (flat1.f:65-68)
 //   layer i used as half space: hsf_i = a/r_i, hsr_i = (1/hsf_i)^pwr (flat1.f:58-62)
+// The flattening factors difference nearly equal radii, which amplifies a 1-ulp difference between
+// two powf/logf implementations to ~1e-3 of a thin layer's density/thickness.  Evaluate in fp64 and
+// round once: that is the correctly rounded fp32 result, which is also what the reference's libm
+// returns (glibc powf/logf are correctly rounded in all but vanishingly rare cases).
+SD_HD __forceinline__ float powr32(float x, float y) { return (float)pow((double)x, (double)y); }
+SD_HD __forceinline__ float log32(float x) { return (float)log((double)x); }
+
 template <int KIND>
-__global__ __launch_bounds__(256) void surfdisp_prep_kernel(PrepArgs A)
+SD_HD inline void prep_stack(const PrepArgs &A, const int b)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= A.B) return;
     const int Lmax = A.Lmax, B = A.B;
     int n = A.nlay ? A.nlay[b] : Lmax;
     const float *src = A.model + (size_t)b * 5 * Lmax;
     float *mdl = A.mdl;
     bool ok = (n >= 2) && (n <= Lmax);
     const float pwr = pwr_of(KIND);
-    const float apw = powf(R0, pwr);
+    const float apw = powr32(R0, pwr);
     if (ok) {
         float hs = 0.0f;          // running thickness sum, fp32 in layer order (flat1.f:33-37)
         float r_i = R0;           // radius of the top of layer i
@@ -64,24 +72,24 @@ __global__ __launch_bounds__(256) void surfdisp_prep_kernel(PrepArgs A)
         for (int i = 0; i < n; ++i) {
             const float vp = src[0 * Lmax + i], vs = src[1 * Lmax + i], rho = src[2 * Lmax + i];
             const float h = src[3 * Lmax + i], qs = src[4 * Lmax + i];
-            if (!(isfinite(vp) && isfinite(vs) && isfinite(rho) && isfinite(h) && isfinite(qs)) ||
+            if (!(fin(vp) && fin(vs) && fin(rho) && fin(h) && fin(qs)) ||
                 !(vp > 0.0f) || !(rho > 0.0f) || (vs < 0.0f) || (h < 0.0f))
                 ok = false;
             hs = hs + h;
             const float r_n = R0 - hs;                       // radius of the bottom of layer i
             float dif = 0.0f, qqq = 0.0f, dfl = 0.0f;
             if (i < n - 1) {
-                const float fltd = logf(r_i / r_n);
+                const float fltd = log32(r_i / r_n);
                 dif = (1.0f / r_n - 1.0f / r_i) * R0 / fltd;
-                const float difr = powf(r_i, pwr) - powf(r_n, pwr);
+                const float difr = powr32(r_i, pwr) - powr32(r_n, pwr);
                 qqq = difr / (fltd * apw * pwr);
-                const float z_n = R0 * logf(R0 / r_n);
+                const float z_n = R0 * log32(R0 / r_n);
                 dfl = z_n - z_i;
                 z_i = z_n;
-                if (!(r_n > 0.0f) || !isfinite(dif) || !isfinite(qqq)) ok = false;
+                if (!(r_n > 0.0f) || !fin(dif) || !fin(qqq)) ok = false;
             }
             const float hsf = R0 / r_i;
-            const float hsr = powf(1.0f / hsf, pwr);
+            const float hsr = powr32(1.0f / hsf, pwr);
             const size_t o = (size_t)i * B + b;
             const size_t fs = (size_t)Lmax * B;
             mdl[F_VP * fs + o] = vp;   mdl[F_VS * fs + o] = vs;   mdl[F_RHO * fs + o] = rho;
@@ -94,12 +102,20 @@ __global__ __launch_bounds__(256) void surfdisp_prep_kernel(PrepArgs A)
     A.nl[b] = ok ? n : 0;          // 0 => BADMODEL: K1/K2 write zeros
 }
 
+template <int KIND>
+__global__ __launch_bounds__(256) void surfdisp_prep_kernel(PrepArgs A)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < A.B) prep_stack<KIND>(A, b);
+}
+
 // per-period, per-layer working values (calcul.f:112-131 then flat1 with n_flat layers)
 struct LayerV { float a, b, rho, d; };
 
-__device__ __forceinline__ LayerV layer_at(const float *__restrict__ mdl, size_t fs, size_t o,
+SD_HD __forceinline__ LayerV layer_at(const float *__restrict__ mdl, size_t fs, size_t o,
                                            float lnT, bool is_halfspace)
 {
+#pragma clang fp contract(off)   // bit-identical at every call site (K2 integrates twice)
     const float a_ref = mdl[F_VP * fs + o], b_ref = mdl[F_VS * fs + o];
     const float rho_ref = mdl[F_RHO * fs + o], qs = mdl[F_QS * fs + o];
     const float qsq = qs * lnT / PI_REF;                                   // calcul.f:122
@@ -417,6 +433,10 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         const int lastl = tbase + G - 1;
         const float l_c = __shfl(cj, lastl), l_d = __shfl(val, lastl);
         const float v0 = __shfl(val, tbase), v1 = __shfl(val, (G > 1) ? tbase + 1 : tbase);
+        const int nxt = (src < lastl) ? src + 1 : lastl;       // right neighbour of the crossing lane
+        const float e_nc = __shfl(cj, nxt), e_nd = __shfl(val, nxt);
+        const int pl = (G > 1) ? lastl - 1 : lastl;            // lane before the last one
+        const float pl_c = __shfl(cj, pl), pl_d = __shfl(val, pl);
 
         bool solved = false, failed = false;
         if (st == ST_SCAN) {
@@ -431,18 +451,39 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
                 if (passes > 100000) failed = true;            // cannot happen: c grows by dc/pass
             }
         } else if (st == ST_REFINE) {
-            if (fl >= 0) { p0c = e_pc; p0d = e_pd; cb = e_c; db = e_d; }
-            else         { p0c = l_c;  p0d = l_d; }
-            if (!(cb - p0c > A.wtol)) {
-                // last step: secant through the bracket ends (error ~ w^2 |D''/D'| / 8)
-                float cr = p0c - p0d * (cb - p0c) / (db - p0d);
-                if (!(cr >= p0c)) cr = p0c;
-                if (!(cr <= cb)) cr = cb;
-                croot = cr;
-                if (croot <= W_B(mm_frozen - 1)) {             // calcul.f:191
-                    if (KIND == 2) { st = ST_ELLIP; sub = 0; }
-                    else solved = true;
-                } else failed = true;
+            // new bracket + one more known point next to it (for the final 3-point step)
+            float tc, td;
+            const float oa = p0c, oda = p0d, ob = cb, odb = db;
+            if (fl >= 0) {
+                p0c = e_pc; p0d = e_pd; cb = e_c; db = e_d;
+                if (fl < lastl) { tc = e_nc; td = e_nd; } else { tc = ob; td = odb; }
+            } else {
+                p0c = l_c; p0d = l_d;
+                if (G > 1) { tc = pl_c; td = pl_d; } else { tc = oa; td = oda; }
+            }
+            {
+                // Candidate root by inverse quadratic interpolation through the bracket ends and the
+                // neighbouring point (offsets from the low end keep fp32 exact enough) and by the
+                // secant.  Accept when the bracket is narrow AND the two agree (the secular function
+                // is locally smooth, so the 3-point estimate is far better than their difference), or
+                // when the bracket has shrunk to NEVILL's own tolerance (surfa.f:10,44).  Otherwise
+                // subdivide again: near osculating modes Delta(c) is strongly curved and only a tight
+                // bracket pins the root the reference finds.
+                const float w = cb - p0c, sx = tc - p0c;
+                const float f0 = p0d, f1 = db, f2 = td;
+                float ts = -f0 * w / (f1 - f0);
+                float t = w * (f0 * f2) / ((f1 - f0) * (f1 - f2)) + sx * (f0 * f1) / ((f2 - f0) * (f2 - f1));
+                if (!(ts >= 0.0f)) ts = 0.0f;
+                if (!(ts <= w)) ts = w;
+                const bool inside = (t >= 0.0f) && (t <= w);
+                const bool agree = inside && (fabsf(t - ts) <= A.atol);
+                if (!(w > 1.0e-6f) || (!(w > A.wtol) && agree)) {
+                    croot = p0c + (inside ? t : ts);
+                    if (croot <= W_B(mm_frozen - 1)) {             // calcul.f:191
+                        if (KIND == 2) { st = ST_ELLIP; sub = 0; }
+                        else solved = true;
+                    } else failed = true;
+                }
             }
         } else if (st == ST_ELLIP) {
             if (G == 1) {
@@ -490,7 +531,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
 struct Drop { int hs_layer; int nreg_hs; };
 
 template <int KIND>
-__device__ __forceinline__ Drop drop_group(const float *__restrict__ mdl, size_t fs, int B, int b,
+SD_HD __forceinline__ Drop drop_group(const float *__restrict__ mdl, size_t fs, int B, int b,
                                            int n, float lnT, float c, float T, int ndiv, bool water,
                                            float div)
 {
@@ -526,31 +567,38 @@ __device__ __forceinline__ Drop drop_group(const float *__restrict__ mdl, size_t
 // ---- Rayleigh, surfa.f:714-1192 ---------------------------------------------------------------
 struct RCoef { float a12, a13, a21, a24, a31, a34, a42, a43, ddz; };
 
-__device__ __forceinline__ void rk4_step(const RCoef &q, double &ur, double &uz, double &tz, double &tr)
+SD_HD __forceinline__ void rk4_step(const RCoef &q, double &ur, double &uz, double &tz, double &tr)
 {
-    // classical RK4 with the reference's fp32 weights (surfa.f:764-771, 955-968)
-    const float w_half = 0.5f * q.ddz, w_one = 1.0f * q.ddz;
-    const float t6 = (1.0f / 6.0f) * q.ddz, t3 = (1.0f / 3.0f) * q.ddz;
+    // classical RK4 with the reference's fp32 weights (surfa.f:764-771, 955-968).
+    // Written with EXPLICIT fma() and contraction off: group_rayleigh() integrates the same
+    // solutions twice (surface values first, energy integrals second) and the two sweeps must be
+    // bit-identical -- the combination xnorm*y+z cancels ~1e6, so a compiler that fuses one
+    // instantiation differently from the other would destroy the integrals.
+#pragma clang fp contract(off)
+    const double w_half = (double)(0.5f * q.ddz), w_one = (double)(1.0f * q.ddz);
+    const double t6 = (double)((1.0f / 6.0f) * q.ddz), t3 = (double)((1.0f / 3.0f) * q.ddz);
+    const double a12 = q.a12, a13 = q.a13, a21 = q.a21, a24 = q.a24, a31 = q.a31, a34 = q.a34,
+                 a42 = q.a42, a43 = q.a43;
     double d1, d2, d3, d4, e1, e2, e3, e4, s1, s2, s3, s4;
     // stage 1 (wwt = 0)
-    d1 = q.a31 * uz + q.a34 * tr; d2 = q.a12 * tz + q.a13 * ur;
-    d3 = q.a21 * uz + q.a24 * tr; d4 = q.a42 * tz + q.a43 * ur;
-    e1 = ur + t6 * d1; e2 = uz + t6 * d2; e3 = tz + t6 * d3; e4 = tr + t6 * d4;
+    d1 = fma(a31, uz, a34 * tr); d2 = fma(a12, tz, a13 * ur);
+    d3 = fma(a21, uz, a24 * tr); d4 = fma(a42, tz, a43 * ur);
+    e1 = fma(t6, d1, ur); e2 = fma(t6, d2, uz); e3 = fma(t6, d3, tz); e4 = fma(t6, d4, tr);
     // stage 2
-    s1 = ur + w_half * d1; s2 = uz + w_half * d2; s3 = tz + w_half * d3; s4 = tr + w_half * d4;
-    d1 = q.a31 * s2 + q.a34 * s4; d2 = q.a12 * s3 + q.a13 * s1;
-    d3 = q.a21 * s2 + q.a24 * s4; d4 = q.a42 * s3 + q.a43 * s1;
-    e1 += t3 * d1; e2 += t3 * d2; e3 += t3 * d3; e4 += t3 * d4;
+    s1 = fma(w_half, d1, ur); s2 = fma(w_half, d2, uz); s3 = fma(w_half, d3, tz); s4 = fma(w_half, d4, tr);
+    d1 = fma(a31, s2, a34 * s4); d2 = fma(a12, s3, a13 * s1);
+    d3 = fma(a21, s2, a24 * s4); d4 = fma(a42, s3, a43 * s1);
+    e1 = fma(t3, d1, e1); e2 = fma(t3, d2, e2); e3 = fma(t3, d3, e3); e4 = fma(t3, d4, e4);
     // stage 3
-    s1 = ur + w_half * d1; s2 = uz + w_half * d2; s3 = tz + w_half * d3; s4 = tr + w_half * d4;
-    d1 = q.a31 * s2 + q.a34 * s4; d2 = q.a12 * s3 + q.a13 * s1;
-    d3 = q.a21 * s2 + q.a24 * s4; d4 = q.a42 * s3 + q.a43 * s1;
-    e1 += t3 * d1; e2 += t3 * d2; e3 += t3 * d3; e4 += t3 * d4;
+    s1 = fma(w_half, d1, ur); s2 = fma(w_half, d2, uz); s3 = fma(w_half, d3, tz); s4 = fma(w_half, d4, tr);
+    d1 = fma(a31, s2, a34 * s4); d2 = fma(a12, s3, a13 * s1);
+    d3 = fma(a21, s2, a24 * s4); d4 = fma(a42, s3, a43 * s1);
+    e1 = fma(t3, d1, e1); e2 = fma(t3, d2, e2); e3 = fma(t3, d3, e3); e4 = fma(t3, d4, e4);
     // stage 4
-    s1 = ur + w_one * d1; s2 = uz + w_one * d2; s3 = tz + w_one * d3; s4 = tr + w_one * d4;
-    d1 = q.a31 * s2 + q.a34 * s4; d2 = q.a12 * s3 + q.a13 * s1;
-    d3 = q.a21 * s2 + q.a24 * s4; d4 = q.a42 * s3 + q.a43 * s1;
-    ur = e1 + t6 * d1; uz = e2 + t6 * d2; tz = e3 + t6 * d3; tr = e4 + t6 * d4;
+    s1 = fma(w_one, d1, ur); s2 = fma(w_one, d2, uz); s3 = fma(w_one, d3, tz); s4 = fma(w_one, d4, tr);
+    d1 = fma(a31, s2, a34 * s4); d2 = fma(a12, s3, a13 * s1);
+    d3 = fma(a21, s2, a24 * s4); d4 = fma(a42, s3, a43 * s1);
+    ur = fma(t6, d1, e1); uz = fma(t6, d2, e2); tz = fma(t6, d3, e3); tr = fma(t6, d4, e4);
 }
 
 struct RInt {                       // energy integrals, fp64 accumulators (reference: fp32 sumi*)
@@ -560,12 +608,13 @@ struct RInt {                       // energy integrals, fp64 accumulators (refe
 // integrate both solutions from the half space to the surface.  INTEG: also accumulate the Boole
 // energy integrals of the combined solution (xnorm*y + z)/bb (surfa.f:1087-1129).
 template <bool INTEG>
-__device__ __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t fs, int B, int b,
+SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t fs, int B, int b,
                                                int n, float lnT, int ndiv, bool water, float div,
                                                const Drop dr, float wvno, float wvnosq, float omegsq,
                                                double y[4], double z[4], bool do_y,
                                                double xnorm, double bbn, RInt &acc)
 {
+#pragma clang fp contract(off)   // both sweeps must see identical coefficients
     for (int jl = dr.hs_layer; jl >= 0; --jl) {
         const int nsub = (jl == 0 && water) ? 1 : ndiv;
         const int nreg = (jl == dr.hs_layer) ? dr.nreg_hs : nsub;
@@ -619,9 +668,10 @@ __device__ __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, si
     }
 }
 
-__device__ float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
-                                float T, float c, float ratio)
+SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
+                                float T, float c, float ratio, double *dbg = nullptr)
 {
+#pragma clang fp contract(off)
     const float lnT = logf(1.0f / T);
     int ndiv = 5;
     const int ivre = 99 / (n - 1);                                    // surfa.f:783-784
@@ -687,6 +737,7 @@ __device__ float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B,
     rayleigh_sweep<false>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
                           y, z, true, 0.0, 1.0, acc);
     const double yt[4] = {y[0], y[1], y[2], y[3]};
+    if (dbg) { for (int i = 0; i < 4; ++i) { dbg[i] = y[i]; dbg[4 + i] = z[i]; } dbg[12] = dr.hs_layer; dbg[13] = dr.nreg_hs; dbg[14] = ndiv; }
     double xnorm, bbn;
     {   // surfa.f:1056-1069
         double aa = z[0] - ratio * z[1];
@@ -712,6 +763,7 @@ __device__ float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B,
             bbn = bb;
         }
     }
+    if (dbg) { dbg[8] = xnorm; dbg[9] = bbn; }
     // pass 2: same integration again (bit-identical values), now with the energy integrals
     for (int i = 0; i < 4; ++i) { y[i] = y0[i]; z[i] = z0[i]; }
     // half-space analytic terms use the combined vector at the top of the half space
@@ -740,12 +792,13 @@ __device__ float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B,
         acc.i1 += (xlamb + 2.0f * xmu) * dmmr + xmu * dmmz;
         acc.i2 += xmu * dzsr - xlamb * drsz;
     }
+    if (dbg) { dbg[10] = acc.i0; dbg[11] = acc.i1; dbg[15] = acc.i2; }
     const float s0 = (float)acc.i0, s1 = (float)acc.i1, s2 = (float)acc.i2;
     return (wvno * s1 + s2) / (omega * s0);                           // surfa.f:1186
 }
 
 // ---- Love, surfa.f:374-606 (all fp32, as the reference) --------------------------------------
-__device__ float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
+SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
                             float T, float c)
 {
     const float lnT = logf(1.0f / T);
@@ -841,7 +894,8 @@ __global__ __launch_bounds__(256) void surfdisp_group_kernel(GroupArgs A)
     const float T = A.per[k];
     const float c = A.c[o];
     float ugr;
-    if (KIND == 2) ugr = group_rayleigh(A.mdl, fs, B, b, n, T, c, A.ratio[(size_t)k * B + b]);
+    if (KIND == 2) ugr = group_rayleigh(A.mdl, fs, B, b, n, T, c, A.ratio[(size_t)k * B + b],
+                                        A.dbg ? A.dbg + 16 * o : nullptr);
     else           ugr = group_love(A.mdl, fs, B, b, n, T, c);
     A.u[o] = ugr;
 }

@@ -88,7 +88,12 @@ class BatchPlan:
         self.u = torch.zeros(self.B, self.P, dtype=torch.float32, device=self.device)
         self.status = torch.zeros(self.B, dtype=torch.int32, device=self.device)
 
-    def run(self, model, periods, kind=2, nlay=None):
+    def run_timed(self, model, periods, kind=2, nlay=None):
+        """As run(), but blocks and also returns the (prep, phase, group) kernel durations in ms,
+        measured with HIP events on the launch stream (surfdisp_forward_batch_device_timed)."""
+        return self.run(model, periods, kind=kind, nlay=nlay, _timed=True)
+
+    def run(self, model, periods, kind=2, nlay=None, _timed=False):
         torch = self.torch
         for t, shape in ((model, (self.B, 5, self.L)), (periods, (self.P,))):
             if (t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shape
@@ -98,14 +103,19 @@ class BatchPlan:
                                  or nlay.device != self.device):
             raise ValueError("nlay must be int32 [B] on the same device")
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        with torch.cuda.device(self.device):
-            rc = _lib.lib().surfdisp_forward_batch_device(
-                ctypes.c_void_p(stream), self.B, self.L,
+        args = [ctypes.c_void_p(stream), self.B, self.L,
                 ctypes.c_void_p(nlay.data_ptr() if nlay is not None else 0),
                 ctypes.c_void_p(model.data_ptr()), self.P, ctypes.c_void_p(periods.data_ptr()),
                 int(kind), ctypes.c_void_p(self.c.data_ptr()), ctypes.c_void_p(self.u.data_ptr()),
                 ctypes.c_void_p(self.status.data_ptr()), ctypes.c_void_p(self.workspace.data_ptr()),
-                self.ws_bytes)
+                self.ws_bytes]
+        with torch.cuda.device(self.device):
+            if _timed:
+                ms = (ctypes.c_float * 3)()
+                rc = _lib.lib().surfdisp_forward_batch_device_timed(*args, ms)
+                _lib.check(rc)
+                return self.c, self.u, self.status, tuple(float(x) for x in ms)
+            rc = _lib.lib().surfdisp_forward_batch_device(*args)
         _lib.check(rc)
         return self.c, self.u, self.status
 
