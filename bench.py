@@ -39,7 +39,11 @@ def cpu_baseline(per):
     """Bounded CPU sample on the host cores (rank 0, N=1 only).  Checker code, timed - never the product."""
     from pysurfinv_amd import synth
     from oracle import cport, refso
-    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, int(os.environ.get("SURFDISP_CPU_THREADS", "64"))))
     out = {}
     sample = synth.synth_models(8192, NLAY, seed=0)
     if refso.available():

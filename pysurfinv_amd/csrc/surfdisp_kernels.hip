@@ -352,6 +352,8 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
     float p0c = 0.0f, p0d = 0.0f;      // "previous point" of lane 0: scan carry or bracket low end
     float cb = 0.0f, db = 0.0f;        // bracket high end (refine)
     float croot = 0.0f, r12 = 0.0f;
+    int p0mm = 0;                      // effective half space the value p0d was computed with
+    bool p0ok = false;                 // p0d was computed with mm_frozen (usable for interpolation)
     bool first = true;
     int status = SURFDISP_OK;
 
@@ -416,6 +418,8 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         const float sc = __shfl(cj, lm1), sv_ = __shfl(val, lm1);
         const float pc = (j == 0) ? p0c : sc;
         const float pd = (j == 0) ? p0d : sv_;
+        const int smm = __shfl(mmj, lm1);
+        const int pmm = (j == 0) ? p0mm : smm;
         const bool searching = (st == ST_SCAN) || (st == ST_REFINE);
         const bool has_prev = !((st == ST_SCAN) && first && (j == 0));
         const bool cross = has_prev && (signbit(val) != signbit(pd));
@@ -429,6 +433,8 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         const float e_c = __shfl(cj, src), e_d = __shfl(val, src);
         const float e_pc = __shfl(pc, src), e_pd = __shfl(pd, src);
         const int e_mm = __shfl(mmj, src);
+        const int e_pmm = __shfl(pmm, src);
+        const int l_mm = __shfl(mmj, tbase + G - 1);
         const int e_cross = __shfl((int)cross, src);
         const int lastl = tbase + G - 1;
         const float l_c = __shfl(cj, lastl), l_d = __shfl(val, lastl);
@@ -443,23 +449,30 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
             ++passes;
             if (fl >= 0 && e_cross) {                          // bracket found -> refine
                 p0c = e_pc; p0d = e_pd; cb = e_c; db = e_d; mm_frozen = e_mm;
+                // the low end was evaluated with ITS OWN layer dropping (idrop=0 per scan trial); if
+                // that differs from the frozen one its magnitude belongs to a different function
+                // and only its sign may be used (NEVILL's 10x guard, surfa.f:47-51, covers this)
+                p0ok = (e_pmm == e_mm);
                 st = ST_REFINE;
             } else if (fl >= 0) {
                 failed = true;                                 // label 250
             } else {
-                p0c = l_c; p0d = l_d; first = false;
+                p0c = l_c; p0d = l_d; p0mm = l_mm; first = false;
                 if (passes > 100000) failed = true;            // cannot happen: c grows by dc/pass
             }
         } else if (st == ST_REFINE) {
             // new bracket + one more known point next to it (for the final 3-point step)
             float tc, td;
+            bool tok = true;
             const float oa = p0c, oda = p0d, ob = cb, odb = db;
             if (fl >= 0) {
+                if (fl != tbase) p0ok = true;                  // low end replaced by a frozen-mmax point
                 p0c = e_pc; p0d = e_pd; cb = e_c; db = e_d;
                 if (fl < lastl) { tc = e_nc; td = e_nd; } else { tc = ob; td = odb; }
             } else {
-                p0c = l_c; p0d = l_d;
-                if (G > 1) { tc = pl_c; td = pl_d; } else { tc = oa; td = oda; }
+                const bool oaok = p0ok;
+                p0c = l_c; p0d = l_d; p0ok = true;
+                if (G > 1) { tc = pl_c; td = pl_d; } else { tc = oa; td = oda; tok = oaok; }
             }
             {
                 // Candidate root by inverse quadratic interpolation through the bracket ends and the
@@ -475,7 +488,8 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
                 float t = w * (f0 * f2) / ((f1 - f0) * (f1 - f2)) + sx * (f0 * f1) / ((f2 - f0) * (f2 - f1));
                 if (!(ts >= 0.0f)) ts = 0.0f;
                 if (!(ts <= w)) ts = w;
-                const bool inside = (t >= 0.0f) && (t <= w);
+                if (!p0ok) ts = 0.5f * w;                         // magnitudes not comparable: bisect
+                const bool inside = p0ok && tok && (t >= 0.0f) && (t <= w);
                 const bool agree = inside && (fabsf(t - ts) <= A.atol);
                 if (!(w > 1.0e-6f) || (!(w > A.wtol) && agree)) {
                     croot = p0c + (inside ? t : ts);
@@ -507,7 +521,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
                 build(mm_carry);
                 b1top = W_B(0);
                 p0c = 0.90f * croot;                           // calcul.f:143
-                p0d = 0.0f; first = true; passes = 0;
+                p0d = 0.0f; p0mm = 0; p0ok = false; first = true; passes = 0;
                 st = ST_SCAN;
             }
         }
