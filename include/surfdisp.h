@@ -103,7 +103,7 @@ int  surfdisp_get_team(int B, int Lmax);           /* what a launch with (B, Lma
 int  surfdisp_device_count(void);                  /* gfx950 devices visible; <=0: none */
 int  surfdisp_abi_version(void);
 const char *surfdisp_last_error(void);             /* thread-local, never NULL */
-const char *surfdisp_kernel_name(int which);       /* 0 prep, 1 phase (root search), 2 group */
+const char *surfdisp_kernel_name(int which);       /* 0 prep, 1 phase (root search), 2 group, 3 finish */
 
 #ifdef __cplusplus
 }

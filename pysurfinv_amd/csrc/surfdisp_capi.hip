@@ -30,7 +30,7 @@ void set_err(const char *fmt, const char *a = "", const char *b = "")
 size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct Carve {
-    float *mdl, *ratio;
+    float *mdl, *ratio, *ct, *ut;
     int *nl, *nsolved;
     size_t total;
 };
@@ -42,6 +42,8 @@ Carve carve(void *base, int B, int Lmax, int P)
     Carve c;
     c.mdl = reinterpret_cast<float *>(p + off);     off += align_up((size_t)10 * Lmax * B * sizeof(float));
     c.ratio = reinterpret_cast<float *>(p + off);   off += align_up((size_t)P * B * sizeof(float));
+    c.ct = reinterpret_cast<float *>(p + off);      off += align_up((size_t)P * B * sizeof(float));
+    c.ut = reinterpret_cast<float *>(p + off);      off += align_up((size_t)P * B * sizeof(float));
     c.nl = reinterpret_cast<int *>(p + off);        off += align_up((size_t)B * sizeof(int));
     c.nsolved = reinterpret_cast<int *>(p + off);   off += align_up((size_t)B * sizeof(int));
     c.total = off;
@@ -95,6 +97,7 @@ const char *surfdisp_kernel_name(int which)
         case 0: return "surfdisp_prep_kernel";
         case 1: return "surfdisp_phase_kernel";
         case 2: return "surfdisp_group_kernel";
+        case 3: return "surfdisp_finish_kernel";
         default: return "";
     }
 }
@@ -150,11 +153,13 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     float wtol = 1.2e-3f, atol = 1.0e-6f;
     if (const char *e = getenv("SURFDISP_WTOL")) wtol = (float)atof(e);
     if (const char *e = getenv("SURFDISP_ATOL")) atol = (float)atof(e);
-    sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, c, w.ratio, w.nsolved, status, wtol, atol};
+    sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, status, wtol, atol};
     SD_HIP(sd::launch_phase(s, kind, G, ph));
     if (ev) SD_HIP(hipEventRecord(ev[2], s));
-    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, c, w.ratio, w.nsolved, u, g_dbg};
+    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, g_dbg};
     SD_HIP(sd::launch_group(s, kind, ga));
+    sd::FinishArgs fa{B, P, w.ct, w.ut, c, u};
+    SD_HIP(sd::launch_finish(s, fa));
     if (ev) SD_HIP(hipEventRecord(ev[3], s));
     return SURFDISP_SUCCESS;
 }

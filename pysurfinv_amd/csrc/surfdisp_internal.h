@@ -20,7 +20,7 @@ struct PhaseArgs {
     const float *mdl;
     const int *nl;
     const float *per;     // [P]
-    float *c;             // [B][P]
+    float *c;             // [P][B] period-major (internal; transposed by the finish kernel)
     float *ratio;         // [P][B] ellipticity (Rayleigh), input of the group-velocity kernel
     int *nsolved;         // [B]
     int *status;          // [B] or nullptr
@@ -33,14 +33,21 @@ struct GroupArgs {
     const float *mdl;
     const int *nl;
     const float *per;
-    const float *c;
+    const float *c;       // [P][B]
     const float *ratio;
     const int *nsolved;
-    float *u;             // [B][P]
+    float *u;             // [P][B]
     double *dbg;          // nullptr, or [B][P][16] intermediate values (developer builds)
 };
 
+struct FinishArgs {
+    int B, P;
+    const float *ct, *ut; // [P][B]
+    float *c, *u;         // [B][P] caller's arrays
+};
+
 size_t phase_lds_bytes(int Lmax, int G);
+hipError_t launch_finish(hipStream_t s, const FinishArgs &a);
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a);
 hipError_t launch_phase(hipStream_t s, int kind, int G, const PhaseArgs &a);
 hipError_t launch_group(hipStream_t s, int kind, const GroupArgs &a);

@@ -143,36 +143,86 @@ SD_HD __forceinline__ LayerV layer_at(const float *__restrict__ mdl, size_t fs, 
 #define W_B(m) wq[((1 * Lcap + (m)) * S)]
 #define W_R(m) wq[((2 * Lcap + (m)) * S)]
 #define W_D(m) wq[((3 * Lcap + (m)) * S)]
+#define W_IA2(m) wq[((4 * Lcap + (m)) * S)]   // 1/a^2  (c-independent; saves a division per layer per trial)
+#define W_IB2(m) wq[((5 * Lcap + (m)) * S)]   // 1/b^2  (0 for a liquid layer)
+constexpr int NFW = 6;
+
+// ---- fast-but-tight fp32 helpers for the inner recursion --------------------------------------
+// The reference evaluates ~9 IEEE divisions, 2 sqrt and 2-4 libm calls per layer per trial
+// velocity.  Here: reciprocal = v_rcp_f32 + one Newton step (<= 1 ulp), sqrt = v_sqrt_f32 (1 ulp),
+// exp = v_exp_f32 on a split argument (~1 ulp), sincos = 3-constant Cody-Waite reduction + minimax
+// polynomials (~1 ulp for |x| < 1e4).  Every one of these perturbs a matrix entry by ~1e-7
+// relative, i.e. like a 1e-7 relative change of a layer's thickness or velocity -- physically
+// nothing; measured end-to-end parity is unchanged.
+__device__ __forceinline__ float rcp_nr(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(r, fmaf(-x, r, 1.0f), r);
+}
+__device__ __forceinline__ float sqrt_hw(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float exp_sp(float x)
+{
+    // e^x = 2^(x*log2e): split the product so the exponent argument keeps ~fp32 accuracy
+    const float L2E_HI = 1.44269502e+00f, L2E_LO = 1.92596299e-08f;
+    const float t = x * L2E_HI;
+    const float tl = fmaf(x, L2E_HI, -t) + x * L2E_LO;      // low part of x*log2(e)
+    const float ti = __builtin_rintf(t);
+    const float tf = (t - ti) + tl;                          // |tf| <= 0.5 (+eps)
+    const float p = __builtin_amdgcn_exp2f(tf);
+    return __builtin_amdgcn_ldexpf(p, (int)ti);
+}
+__device__ __forceinline__ void sincos_cw(float x, float *sn, float *cs)
+{
+    const float TWO_OVER_PI = 6.36619747e-01f;
+    const float P1 = 1.57079601e+00f, P2 = 3.13916473e-07f, P3 = 5.39030253e-15f;   // pi/2 split (Cody-Waite)
+    const float q = __builtin_rintf(x * TWO_OVER_PI);
+    float r = fmaf(-q, P1, x);
+    r = fmaf(-q, P2, r);
+    r = fmaf(-q, P3, r);
+    const int n = (int)q;
+    const float r2 = r * r;
+    // minimax on [-pi/4, pi/4] (Cephes sinf/cosf coefficients)
+    float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
+    float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
+                    r2 * r2, fmaf(-0.5f, r2, 1.0f));
+    const float s0 = (n & 1) ? pc : ps;
+    const float c0 = (n & 1) ? ps : pc;
+    *sn = (n & 2) ? -s0 : s0;
+    *cs = ((n + 1) & 2) ? -c0 : c0;
+}
 
 // Rayleigh: Dunkin compound-matrix recursion, surfa.f:193-357.  start = 1 -> dispersion
 // (returns -bb1, surfa.f:357); start = 2/3 -> the two ellipticity passes (returns bb1, surfa.f:360-363).
+// Same formulas as the reference; divisions folded into three reciprocals per layer and the
+// c-independent 1/a^2, 1/b^2 taken from LDS.
 __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap, const int S,
                                                 const int mmax, const float c, const float T,
                                                 const int start)
 {
     const float wvno = 6.28318531f / (c * T);
     const float csq = c * c;
+    const float icsq = 1.0f / csq;
     float b1 = (start == 1) ? 1.0f : 0.0f, b2 = (start == 2) ? 1.0f : 0.0f,
           b3 = (start == 3) ? 1.0f : 0.0f, b4 = 0.0f, b5 = 0.0f;
     for (int m = 0; m < mmax - 1; ++m) {
-        const float pv = W_A(m), sv = W_B(m), rho = W_R(m), d = W_D(m);
-        const float arga = 1.0f - csq / (pv * pv);
-        float ra = sqrtf(fabsf(arga));
+        const float sv = W_B(m), rho = W_R(m), d = W_D(m);
+        const float arga = fmaf(-csq, W_IA2(m), 1.0f);               // 1 - c^2/a^2, surfa.f:211
+        float ra = sqrt_hw(fabsf(arga));
         if (arga > 0.0f) ra = -ra;
-        float a11, a12, a13, a14, a15, a21, a22, a23, a24, a31, a32, a33, a41, a42, a51;
+        const float wd = wvno * d;
+        const float rhoc = rho * csq;
         if (!(fabsf(sv) > ACCUR)) {
             // liquid surface layer, surfa.f:216-251 (skipped entirely in the ellipticity passes)
             if (start != 1) continue;
-            const float pm = wvno * ra * d;
-            const float rhoc = rho * csq;
+            const float pm = wd * ra;
             float sinpr, cosp;
-            if (fabsf(ra) < ACCUR) { sinpr = wvno * d; cosp = 1.0f; }
+            if (fabsf(ra) < ACCUR) { sinpr = wd; cosp = 1.0f; }
             else if (ra < 0.0f) {
-                const float ep = expf(pm), em = expf(-pm);
+                const float ep = exp_sp(pm), em = rcp_nr(ep);
                 sinpr = (ep - em) / (2.0f * ra);
                 cosp = 0.5f * (ep + em);
             } else {
-                float sn, cs; sincosf(pm, &sn, &cs);
+                float sn, cs; sincos_cw(pm, &sn, &cs);
                 sinpr = sn / ra; cosp = cs;
             }
             // only a11 and a21 are non-zero (surfa.f:236-250)
@@ -182,62 +232,63 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             b1 = n1; b2 = n2; b3 = 0.0f; b4 = 0.0f; b5 = n5;
             continue;
         }
-        const float argb = 1.0f - csq / (sv * sv);
-        float rb = sqrtf(fabsf(argb));
+        const float argb = fmaf(-csq, W_IB2(m), 1.0f);
+        float rb = sqrt_hw(fabsf(argb));
         if (argb > 0.0f) rb = -rb;
-        const float g = 2.0f * (sv * sv) / csq;
+        const float g = 2.0f * (sv * sv) * icsq;
         const float g1 = g - 1.0f;
-        const float rhoc = rho * csq;
-        const float pm = wvno * ra * d;
-        const float qm = wvno * rb * d;
+        const float irhoc = rcp_nr(rhoc);
+        const float pm = wd * ra;
+        const float qm = wd * rb;
         float rsinp, sinpr, cosp, rsinq, sinqr, cosq;
         if (ra < 0.0f) {                                   // evanescent P, surfa.f:267-269
-            const float ep = expf(pm), em = expf(-pm);
-            rsinp = -ra * 0.5f * (ep - em);
-            sinpr = -rsinp / (ra * ra);
+            const float ep = exp_sp(pm), em = rcp_nr(ep);
+            const float sh = 0.5f * (ep - em);
+            rsinp = -ra * sh;
+            sinpr = sh * rcp_nr(ra);
             cosp = 0.5f * (ep + em);
         } else if (ra == 0.0f) {
-            rsinp = 0.0f; sinpr = wvno * d; cosp = 1.0f;
+            rsinp = 0.0f; sinpr = wd; cosp = 1.0f;
         } else {                                           // oscillatory P, surfa.f:271-273
-            float sn, cs; sincosf(pm, &sn, &cs);
-            rsinp = ra * sn; sinpr = rsinp / (ra * ra); cosp = cs;
+            float sn, cs; sincos_cw(pm, &sn, &cs);
+            rsinp = ra * sn; sinpr = sn * rcp_nr(ra); cosp = cs;
         }
         if (fabsf(rb) < ACCUR) {
-            rsinq = 0.0f; sinqr = wvno * d; cosq = 1.0f;
+            rsinq = 0.0f; sinqr = wd; cosq = 1.0f;
         } else if (rb > 0.0f) {
-            float sn, cs; sincosf(qm, &sn, &cs);
-            rsinq = rb * sn; sinqr = rsinq / (rb * rb); cosq = cs;
+            float sn, cs; sincos_cw(qm, &sn, &cs);
+            rsinq = rb * sn; sinqr = sn * rcp_nr(rb); cosq = cs;
         } else {
-            const float ep = expf(qm), em = expf(-qm);
-            rsinq = -rb * 0.5f * (ep - em);
-            sinqr = -rsinq / (rb * rb);
+            const float ep = exp_sp(qm), em = rcp_nr(ep);
+            const float sh = 0.5f * (ep - em);
+            rsinq = -rb * sh;
+            sinqr = sh * rcp_nr(rb);
             cosq = 0.5f * (ep + em);
         }
-        {   // the fifteen distinct entries, surfa.f:289-320
-            const float rr = rsinp * rsinq, ss = sinpr * sinqr, cc = cosp * cosq;
-            const float rs1 = rsinp * cosq, rs2 = sinqr * cosp, rs3 = sinpr * cosq, rs4 = rsinq * cosp;
-            const float gm = 2.0f * g - 1.0f;
-            const float gs = g * g, g1s = g1 * g1;
-            const float ccm = 1.0f - cc;
-            const float gg1 = g * g1;
-            const float rhocs = rhoc * rhoc;
-            const float suu = gs * rr + g1s * ss;
-            a11 = (2.0f * gs - gm) * cc - suu - 2.0f * gg1;
-            a12 = -(rs1 + rs2) / rhoc;
-            a13 = -2.0f * (gm * ccm + g1 * ss + g * rr) / rhoc;
-            a14 = (rs3 + rs4) / rhoc;
-            a15 = (2.0f * ccm + rr + ss) / rhocs;
-            a21 = rhoc * (g1s * rs3 + gs * rs4);
-            a22 = cc;
-            a23 = 2.0f * (g * rs4 + g1 * rs3);
-            a24 = sinpr * rsinq;
-            a31 = rhoc * (gg1 * gm * ccm + g1s * g1 * ss + gs * g * rr);
-            a32 = g1 * rs2 + g * rs1;
-            a33 = 1.0f + 2.0f * (2.0f * gg1 * ccm + suu);
-            a41 = -rhoc * (g1s * rs2 + gs * rs1);
-            a42 = rsinp * sinqr;
-            a51 = rhocs * (2.0f * gs * g1s * ccm + gs * gs * rr + g1s * g1s * ss);
-        }
+        // the fifteen distinct entries, surfa.f:289-320
+        const float rr = rsinp * rsinq, ss = sinpr * sinqr, cc = cosp * cosq;
+        const float rs1 = rsinp * cosq, rs2 = sinqr * cosp, rs3 = sinpr * cosq, rs4 = rsinq * cosp;
+        const float gm = 2.0f * g - 1.0f;
+        const float gs = g * g, g1s = g1 * g1;
+        const float ccm = 1.0f - cc;
+        const float gg1 = g * g1;
+        const float rhocs = rhoc * rhoc;
+        const float suu = gs * rr + g1s * ss;
+        const float a11 = (2.0f * gs - gm) * cc - suu - 2.0f * gg1;
+        const float a12 = -(rs1 + rs2) * irhoc;
+        const float a13 = -2.0f * (gm * ccm + g1 * ss + g * rr) * irhoc;
+        const float a14 = (rs3 + rs4) * irhoc;
+        const float a15 = (2.0f * ccm + rr + ss) * (irhoc * irhoc);
+        const float a21 = rhoc * (g1s * rs3 + gs * rs4);
+        const float a22 = cc;
+        const float a23 = 2.0f * (g * rs4 + g1 * rs3);
+        const float a24 = sinpr * rsinq;
+        const float a31 = rhoc * (gg1 * gm * ccm + g1s * g1 * ss + gs * g * rr);
+        const float a32 = g1 * rs2 + g * rs1;
+        const float a33 = 1.0f + 2.0f * (2.0f * gg1 * ccm + suu);
+        const float a41 = -rhoc * (g1s * rs2 + gs * rs1);
+        const float a42 = rsinp * sinqr;
+        const float a51 = rhocs * (2.0f * gs * g1s * ccm + gs * gs * rr + g1s * g1s * ss);
         // compound-matrix product with its symmetries, surfa.f:326-330
         const float n1 = a11 * b1 + a12 * b2 + a13 * b3 + a14 * b4 + a15 * b5;
         const float n2 = a21 * b1 + a22 * b2 + a23 * b3 + a24 * b4 - a14 * b5;
@@ -249,22 +300,25 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
     // half-space closure, surfa.f:340-354
     const int mh = mmax - 1;
     const float pp = W_A(mh), sv = W_B(mh), rho = W_R(mh);
-    const float arga = 1.0f - csq / (pp * pp);
-    float ra = sqrtf(fabsf(arga));
+    const float arga = fmaf(-csq, W_IA2(mh), 1.0f);
+    float ra = sqrt_hw(fabsf(arga));
     if (arga > 0.0f) ra = -ra;
-    const float argb = 1.0f - csq / (sv * sv);
-    float rb = sqrtf(fabsf(argb));
+    const float argb = fmaf(-csq, W_IB2(mh), 1.0f);
+    float rb = sqrt_hw(fabsf(argb));
     if (argb > 0.0f) rb = -rb;
-    const float g = 2.0f * (sv * sv) / csq;
+    const float sss = sv * sv, rhp = rho * pp;
+    const float g = 2.0f * sss * icsq;
     const float g1 = g - 1.0f;
-    const float sss = sv * sv, ppp = pp * pp, rhp = rho * pp, gra = g * ra, g1s = g1 * g1;
-    const float rba = rb - 1.0f / ra;
-    const float h11 = -2.0f * rb * sss / ppp + csq * g1s / ppp / gra;
-    const float t12 = rhp * pp;
-    const float h13 = -rb / t12 + g1 / t12 / gra;
-    const float h14 = rb / t12 / gra;
-    const float h15 = rba / rhp / rhp / csq / g;
-    const float h12 = -1.0f / g / t12;
+    const float gra = g * ra, g1s = g1 * g1;
+    const float ira = rcp_nr(ra), igra = rcp_nr(gra), ippp = W_IA2(mh);
+    const float t12 = rhp * pp, it12 = rcp_nr(t12);
+    const float rba = rb - ira;
+    const float h11 = -2.0f * rb * sss * ippp + csq * g1s * ippp * igra;
+    const float h13 = -rb * it12 + g1 * it12 * igra;
+    const float h14 = rb * it12 * igra;
+    const float irhp = rcp_nr(rhp);
+    const float h15 = rba * irhp * irhp * icsq * rcp_nr(g);
+    const float h12 = -rcp_nr(g) * it12;
     const float bb1 = h11 * b1 + h12 * b2 + 2.0f * h13 * b3 + h14 * b4 + h15 * b5;
     return (start == 1) ? -bb1 : bb1;
 }
@@ -274,32 +328,32 @@ __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, con
                                             const int mmax, const float c, const float T)
 {
     const float wvno = 6.2831853f / (c * T);
+    const float csq = c * c;
     const int mh = mmax - 1;
     float bm = W_B(mh);
-    float covb = c / bm;
     float h = W_R(mh) * bm * bm;
-    float rb = sqrtf(fabsf(covb * covb - 1.0f));
+    float rb = sqrt_hw(fabsf(fmaf(csq, W_IB2(mh), -1.0f)));          // sqrt|c^2/b^2 - 1|
     float ut = 1.0f, tt = h * rb;
     for (int m = mh - 1; m >= 0; --m) {
         bm = W_B(m);
         if (bm == 0.0f) continue;                          // water, surfa.f:152
         const float d = W_D(m);
-        covb = c / bm;
-        rb = sqrtf(fabsf(covb * covb - 1.0f));
+        rb = sqrt_hw(fabsf(fmaf(csq, W_IB2(m), -1.0f)));
         h = W_R(m) * bm * bm;
+        const float ih = rcp_nr(h);
         const float q = -wvno * d * rb;
         float y, z, cosq;
         if (rb < 0.1e-20f || c == bm) { y = -wvno * d; z = 0.0f; cosq = 1.0f; }
         else if (c < bm) {
-            const float ep = expf(q), em = 1.0f / ep;
-            y = (ep - em) / (2.0f * rb);
+            const float ep = exp_sp(q), em = rcp_nr(ep);
+            y = (ep - em) * (0.5f * rcp_nr(rb));
             z = -rb * rb * y;
-            cosq = (ep + em) / 2.0f;
+            cosq = (ep + em) * 0.5f;
         } else {
-            float sn, cs; sincosf(q, &sn, &cs);
-            y = sn / rb; z = rb * sn; cosq = cs;
+            float sn, cs; sincos_cw(q, &sn, &cs);
+            y = sn * rcp_nr(rb); z = rb * sn; cosq = cs;
         }
-        const float eut = cosq * ut - y * tt / h;
+        const float eut = cosq * ut - y * tt * ih;
         const float ett = h * z * ut + cosq * tt;
         ut = eut; tt = ett;
     }
@@ -365,6 +419,8 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         for (int i = j; i < nflat; i += G) {
             const LayerV v = layer_at(mdl, fs, (size_t)i * B + b, lnT, i == nflat - 1);
             W_A(i) = v.a; W_B(i) = v.b; W_R(i) = v.rho; W_D(i) = v.d;
+            W_IA2(i) = 1.0f / (v.a * v.a);
+            W_IB2(i) = (v.b > 0.0f) ? 1.0f / (v.b * v.b) : 0.0f;
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -374,7 +430,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
     if (st != ST_DONE) {
         T = A.per[0];
         // clear the slot (a new process sees zeroed COMMON /d/)
-        for (int i = j; i < Lcap; i += G) { W_A(i) = 0.0f; W_B(i) = 0.0f; W_R(i) = 0.0f; W_D(i) = 0.0f; }
+        for (int i = j; i < Lcap; i += G) { W_A(i) = 0.0f; W_B(i) = 0.0f; W_R(i) = 0.0f; W_D(i) = 0.0f; W_IA2(i) = 0.0f; W_IB2(i) = 0.0f; }
         build(n);
         b1top = W_B(0);
         // first guess, fast_surf.f:157-171
@@ -510,7 +566,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         }
         if (solved) {
             if (j == 0) {
-                A.c[(size_t)b * P + k] = croot;
+                A.c[(size_t)k * B + b] = croot;                // period-major: coalesced across teams
                 if (KIND == 2) A.ratio[(size_t)k * B + b] = r12;
             }
             nsolved = ++k;
@@ -532,7 +588,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
     }
     if (b < B && j == 0) {
         if (n < 2) status = SURFDISP_BADMODEL;
-        for (int q = nsolved; q < P; ++q) A.c[(size_t)b * P + q] = 0.0f;
+        for (int q = nsolved; q < P; ++q) A.c[(size_t)q * B + b] = 0.0f;
         A.nsolved[b] = nsolved;
         if (A.status) A.status[b] = status;
     }
@@ -619,8 +675,74 @@ struct RInt {                       // energy integrals, fp64 accumulators (refe
     double i0, i1, i2;
 };
 
-// integrate both solutions from the half space to the surface.  INTEG: also accumulate the Boole
-// energy integrals of the combined solution (xnorm*y + z)/bb (surfa.f:1087-1129).
+// One RK4 step of a constant-coefficient linear system is a fixed linear map.  With the state split
+// as x = (ur, tz), w = (uz, tr) the system matrix is block anti-diagonal (x' = M1 w, w' = M2 x), so
+//   P = I + k1 A + k2 A^2 + k3 A^3 + k4 A^4 = [[I + k2 N1 + k4 N1^2,  k1 M1 + k3 N1 M1],
+//                                             [k1 M2 + k3 N2 M2,  I + k2 N2 + k4 N2^2]],
+// N1 = M1 M2, N2 = M2 M1.  k1..k4 are formed from the reference's fp32 weights exactly as its stage
+// recursion combines them (surfa.f:764-771, 955-968), so P reproduces the reference's step to fp64
+// rounding at a quarter of the arithmetic; all sublayers of a layer share it.
+struct M2x2 { double a, b, c, d; };     // [[a b],[c d]]
+SD_HD __forceinline__ M2x2 mm(const M2x2 &x, const M2x2 &y)
+{
+#pragma clang fp contract(off)
+    M2x2 r;
+    r.a = fma(x.a, y.a, x.b * y.c); r.b = fma(x.a, y.b, x.b * y.d);
+    r.c = fma(x.c, y.a, x.d * y.c); r.d = fma(x.c, y.b, x.d * y.d);
+    return r;
+}
+SD_HD __forceinline__ M2x2 madd(const M2x2 &x, const M2x2 &y)
+{
+    M2x2 r; r.a = x.a + y.a; r.b = x.b + y.b; r.c = x.c + y.c; r.d = x.d + y.d; return r;
+}
+struct RProp { M2x2 p11, p12, p21, p22; };
+
+SD_HD __forceinline__ RProp make_prop(const RCoef &q)
+{
+#pragma clang fp contract(off)
+    const double wh = (double)(0.5f * q.ddz), w1 = (double)(1.0f * q.ddz);
+    const double t6 = (double)((1.0f / 6.0f) * q.ddz), t3 = (double)((1.0f / 3.0f) * q.ddz);
+    const double k1 = (t6 + t3) + (t3 + t6);
+    const double k2 = (t3 * wh + t3 * wh) + t6 * w1;
+    const double k3 = t3 * wh * wh + t6 * w1 * wh;
+    const double k4 = t6 * w1 * wh * wh;
+    const M2x2 m1 = {(double)q.a31, (double)q.a34, (double)q.a21, (double)q.a24};
+    const M2x2 m2 = {(double)q.a13, (double)q.a12, (double)q.a43, (double)q.a42};
+    const M2x2 n1 = mm(m1, m2), n2 = mm(m2, m1);
+    const M2x2 n1s = mm(n1, n1), n2s = mm(n2, n2);
+    const M2x2 n1m1 = mm(n1, m1), n2m2 = mm(n2, m2);
+    RProp P;
+    P.p11 = {1.0 + (k2 * n1.a + k4 * n1s.a), k2 * n1.b + k4 * n1s.b, k2 * n1.c + k4 * n1s.c, 1.0 + (k2 * n1.d + k4 * n1s.d)};
+    P.p22 = {1.0 + (k2 * n2.a + k4 * n2s.a), k2 * n2.b + k4 * n2s.b, k2 * n2.c + k4 * n2s.c, 1.0 + (k2 * n2.d + k4 * n2s.d)};
+    P.p12 = {k1 * m1.a + k3 * n1m1.a, k1 * m1.b + k3 * n1m1.b, k1 * m1.c + k3 * n1m1.c, k1 * m1.d + k3 * n1m1.d};
+    P.p21 = {k1 * m2.a + k3 * n2m2.a, k1 * m2.b + k3 * n2m2.b, k1 * m2.c + k3 * n2m2.c, k1 * m2.d + k3 * n2m2.d};
+    return P;
+}
+SD_HD __forceinline__ RProp prop_sq(const RProp &P)
+{
+    RProp Q;
+    Q.p11 = madd(mm(P.p11, P.p11), mm(P.p12, P.p21));
+    Q.p12 = madd(mm(P.p11, P.p12), mm(P.p12, P.p22));
+    Q.p21 = madd(mm(P.p21, P.p11), mm(P.p22, P.p21));
+    Q.p22 = madd(mm(P.p21, P.p12), mm(P.p22, P.p22));
+    return Q;
+}
+// v = (ur, uz, tz, tr)
+SD_HD __forceinline__ void prop_apply(const RProp &P, double v[4])
+{
+#pragma clang fp contract(off)
+    const double ur = v[0], uz = v[1], tz = v[2], tr = v[3];
+    v[0] = fma(P.p11.a, ur, P.p11.b * tz) + fma(P.p12.a, uz, P.p12.b * tr);
+    v[2] = fma(P.p11.c, ur, P.p11.d * tz) + fma(P.p12.c, uz, P.p12.d * tr);
+    v[1] = fma(P.p21.a, ur, P.p21.b * tz) + fma(P.p22.a, uz, P.p22.b * tr);
+    v[3] = fma(P.p21.c, ur, P.p21.d * tz) + fma(P.p22.c, uz, P.p22.d * tr);
+}
+
+// integrate both solutions from the half space to the surface.  INTEG = false: only the surface
+// values are wanted, so each sublayer is one application of P^4.  INTEG = true: step by step, and
+// accumulate the Boole energy integrals of the combined solution (xnorm*y + z)/bb
+// (surfa.f:1087-1129).  The two sweeps agree to fp64 rounding (~1e-15 relative), far inside what the
+// ~1e6 cancellation of the combination needs.
 template <bool INTEG>
 SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t fs, int B, int b,
                                                int n, float lnT, int ndiv, bool water, float div,
@@ -647,6 +769,15 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
         q.a34 = 1.0f / xmu;
         q.a42 = -q.a13;
         q.a43 = q.a21 + 4.0f * wvnosq * xmu * (xlamb + xmu) * q.a12;
+        const RProp P = make_prop(q);
+        if (!INTEG) {
+            const RProp P4 = prop_sq(prop_sq(P));
+            for (int s = 0; s < nreg; ++s) {
+                if (do_y) prop_apply(P4, y);
+                prop_apply(P4, z);
+            }
+            continue;
+        }
         const float dz = dsub / 4.0f;
         const float l2m = xlamb + 2.0f * xmu;
         for (int s = 0; s < nreg; ++s) {
@@ -661,23 +792,21 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
                 f_mr[kk] = aur * aur; f_mz[kk] = auz * auz;
                 f_rz[kk] = aur * duzdz; f_zr[kk] = auz * durdz;
             };
-            if (INTEG) knot(4);
+            knot(4);
 #pragma unroll
             for (int kk = 3; kk >= 0; --kk) {
-                if (do_y) rk4_step(q, y[0], y[1], y[2], y[3]);
-                rk4_step(q, z[0], z[1], z[2], z[3]);
-                if (INTEG) knot(kk);
+                if (do_y) prop_apply(P, y);
+                prop_apply(P, z);
+                knot(kk);
             }
-            if (INTEG) {
-                const float hq = dz / 22.5f;
+            const float hq = dz / 22.5f;
 #define SD_BOOLE(v) (hq * (7.0f * (v[0] + v[4]) + 32.0f * (v[1] + v[3]) + 12.0f * v[2]))
-                const double dmmr = SD_BOOLE(f_mr), dmmz = SD_BOOLE(f_mz);
-                const double drsz = SD_BOOLE(f_rz), dzsr = SD_BOOLE(f_zr);
+            const double dmmr = SD_BOOLE(f_mr), dmmz = SD_BOOLE(f_mz);
+            const double drsz = SD_BOOLE(f_rz), dzsr = SD_BOOLE(f_zr);
 #undef SD_BOOLE
-                acc.i0 += v.rho * (dmmr + dmmz);                        // surfa.f:1126-1128
-                acc.i1 += l2m * dmmr + xmu * dmmz;
-                acc.i2 += xmu * dzsr - xlamb * drsz;
-            }
+            acc.i0 += v.rho * (dmmr + dmmz);                        // surfa.f:1126-1128
+            acc.i1 += l2m * dmmr + xmu * dmmz;
+            acc.i2 += xmu * dzsr - xlamb * drsz;
         }
     }
 }
@@ -901,7 +1030,7 @@ __global__ __launch_bounds__(256) void surfdisp_group_kernel(GroupArgs A)
     const int B = A.B, P = A.P;
     if (idx >= (size_t)B * P) return;
     const int b = (int)(idx % B), k = (int)(idx / B);       // a wavefront = 64 stacks, one period
-    const size_t o = (size_t)b * P + k;
+    const size_t o = idx;                                   // period-major [P][B]: coalesced
     const int n = A.nl[b];
     if (n < 2 || k >= A.nsolved[b]) { A.u[o] = 0.0f; return; }
     const size_t fs = (size_t)A.Lmax * B;
@@ -914,6 +1043,30 @@ __global__ __launch_bounds__(256) void surfdisp_group_kernel(GroupArgs A)
     A.u[o] = ugr;
 }
 
+// K3: period-major internal results -> the caller's [B][P] arrays, through an LDS tile so that both
+// the reads (along b) and the writes (whole rows of consecutive stacks) are coalesced.
+__global__ __launch_bounds__(256) void surfdisp_finish_kernel(FinishArgs A)
+{
+    extern __shared__ float tile[];                 // [64][P+1]
+    const int B = A.B, P = A.P, PS = P + 1;
+    const int b0 = blockIdx.x * 64;
+    const int nb = min(64, B - b0);
+    for (int pass = 0; pass < 2; ++pass) {
+        const float *src = pass ? A.ut : A.ct;
+        float *dst = pass ? A.u : A.c;
+        for (int i = threadIdx.x; i < 64 * P; i += 256) {
+            const int k = i / 64, bl = i % 64;
+            if (bl < nb) tile[bl * PS + k] = src[(size_t)k * B + b0 + bl];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb * P; i += 256) {
+            const int bl = i / P, k = i % P;
+            dst[(size_t)b0 * P + i] = tile[bl * PS + k];
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace sd
 
 // ======================================================================================= launch
@@ -923,7 +1076,7 @@ template <int KIND, int G>
 hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 {
     constexpr int S = 256 / G;
-    const size_t lds = (size_t)4 * a.Lmax * S * sizeof(float);
+    const size_t lds = (size_t)sd::NFW * a.Lmax * S * sizeof(float);
     auto kern = sd::surfdisp_phase_kernel<KIND, G>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -952,7 +1105,7 @@ hipError_t launch_phase_k(hipStream_t s, const sd::PhaseArgs &a, int G)
 
 namespace sd {
 
-size_t phase_lds_bytes(int Lmax, int G) { return (size_t)4 * Lmax * (256 / G) * sizeof(float); }
+size_t phase_lds_bytes(int Lmax, int G) { return (size_t)NFW * Lmax * (256 / G) * sizeof(float); }
 
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a)
 {
@@ -965,6 +1118,14 @@ hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a)
 hipError_t launch_phase(hipStream_t s, int kind, int G, const PhaseArgs &a)
 {
     return kind == 2 ? launch_phase_k<2>(s, a, G) : launch_phase_k<1>(s, a, G);
+}
+
+hipError_t launch_finish(hipStream_t s, const FinishArgs &a)
+{
+    const int grid = (a.B + 63) / 64;
+    const size_t lds = (size_t)64 * (a.P + 1) * sizeof(float);
+    hipLaunchKernelGGL(surfdisp_finish_kernel, dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_group(hipStream_t s, int kind, const GroupArgs &a)
