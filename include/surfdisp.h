@@ -37,6 +37,9 @@ extern "C" {
 
 #define SURFDISP_KIND_LOVE     1   /* == reference kind0 / ilvry */
 #define SURFDISP_KIND_RAYLEIGH 2
+#define SURFDISP_PHASE_ONLY    0x10 /* OR into `kind` of the batched entries: phase velocities only
+                                     * (what Point.misfit consumes, point.py:18); u is not written
+                                     * and may be NULL */
 
 /* per-model status word (the explicit form of the reference's "zeros in c") */
 enum {

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsurfdisp_hip.so")
 SUCCESS, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_WORKSPACE = 0, -1, -2, -3, -4
 OK, PARTIAL, NOROOT, BADMODEL = 0, 1, 2, 4
 KIND_LOVE, KIND_RAYLEIGH = 1, 2
+PHASE_ONLY = 0x10
 NPER_MAX, NLAY_MAX = 200, 200
 
 # every symbol include/surfdisp.h declares

@@ -75,8 +75,10 @@ int pick_team(int B, int Lmax)
 int check_args(int B, int Lmax, int P, int kind, const void *model, const void *per,
                const void *c, const void *u)
 {
+    const int wave = kind & ~SURFDISP_PHASE_ONLY;
     if (B < 1 || Lmax < 2 || Lmax > SURFDISP_NLAY_MAX || P < 1 || P > SURFDISP_NPER_MAX ||
-        (kind != SURFDISP_KIND_LOVE && kind != SURFDISP_KIND_RAYLEIGH) || !model || !per || !c || !u) {
+        (wave != SURFDISP_KIND_LOVE && wave != SURFDISP_KIND_RAYLEIGH) || !model || !per || !c ||
+        (!u && !(kind & SURFDISP_PHASE_ONLY))) {
         set_err("invalid argument (B>=1, 2<=Lmax<=200, 1<=P<=200, kind 1|2, non-null buffers)");
         return SURFDISP_ERR_INVALID;
     }
@@ -143,6 +145,8 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
         return SURFDISP_ERR_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool phase_only = (kind & SURFDISP_PHASE_ONLY) != 0;
+    kind &= ~SURFDISP_PHASE_ONLY;
     const Carve w = carve(workspace, B, Lmax, P);
     const int G = pick_team(B, Lmax);
 
@@ -157,8 +161,8 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     SD_HIP(sd::launch_phase(s, kind, G, ph));
     if (ev) SD_HIP(hipEventRecord(ev[2], s));
     sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, g_dbg};
-    SD_HIP(sd::launch_group(s, kind, ga));
-    sd::FinishArgs fa{B, P, w.ct, w.ut, c, u};
+    if (!phase_only) SD_HIP(sd::launch_group(s, kind, ga));
+    sd::FinishArgs fa{B, P, w.ct, phase_only ? nullptr : w.ut, c, phase_only ? nullptr : u};
     SD_HIP(sd::launch_finish(s, fa));
     if (ev) SD_HIP(hipEventRecord(ev[3], s));
     return SURFDISP_SUCCESS;

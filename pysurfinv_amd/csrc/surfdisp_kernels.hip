@@ -509,6 +509,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
                 // that differs from the frozen one its magnitude belongs to a different function
                 // and only its sign may be used (NEVILL's 10x guard, surfa.f:47-51, covers this)
                 p0ok = (e_pmm == e_mm);
+                passes = 0;
                 st = ST_REFINE;
             } else if (fl >= 0) {
                 failed = true;                                 // label 250
@@ -547,7 +548,8 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
                 if (!p0ok) ts = 0.5f * w;                         // magnitudes not comparable: bisect
                 const bool inside = p0ok && tok && (t >= 0.0f) && (t <= w);
                 const bool agree = inside && (fabsf(t - ts) <= A.atol);
-                if (!(w > 1.0e-6f) || (!(w > A.wtol) && agree)) {
+                ++passes;                                          // hard bound: fp32 cannot resolve <1 ulp
+                if (!(w > 1.0e-6f) || (!(w > A.wtol) && agree) || passes > 64) {
                     croot = p0c + (inside ? t : ts);
                     if (croot <= W_B(mm_frozen - 1)) {             // calcul.f:191
                         if (KIND == 2) { st = ST_ELLIP; sub = 0; }
@@ -780,19 +782,23 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
         }
         const float dz = dsub / 4.0f;
         const float l2m = xlamb + 2.0f * xmu;
+        const double ibb = 1.0 / bbn;                 // one fp64 division per layer instead of 4 per knot
+        const float ixmu = q.a34, il2m = q.a12;       // 1/mu, 1/(lambda+2mu): already formed above
+        float f_mr[5], f_mz[5], f_rz[5], f_zr[5];
+        auto knot = [&](int kk) {
+            const float aur = (float)((xnorm * y[0] + z[0]) * ibb);
+            const float auz = (float)((xnorm * y[1] + z[1]) * ibb);
+            const float atz = (float)((xnorm * y[2] + z[2]) * ibb);
+            const float atr = (float)((xnorm * y[3] + z[3]) * ibb);
+            const float durdz = atr * ixmu - wvno * auz;
+            const float duzdz = (atz + wvno * xlamb * aur) * il2m;
+            f_mr[kk] = aur * aur; f_mz[kk] = auz * auz;
+            f_rz[kk] = aur * duzdz; f_zr[kk] = auz * durdz;
+        };
         for (int s = 0; s < nreg; ++s) {
-            float f_mr[5], f_mz[5], f_rz[5], f_zr[5];
-            auto knot = [&](int kk) {
-                const float aur = (float)((xnorm * y[0] + z[0]) / bbn);
-                const float auz = (float)((xnorm * y[1] + z[1]) / bbn);
-                const float atz = (float)((xnorm * y[2] + z[2]) / bbn);
-                const float atr = (float)((xnorm * y[3] + z[3]) / bbn);
-                const float durdz = atr / xmu - wvno * auz;
-                const float duzdz = (atz + wvno * xlamb * aur) / l2m;
-                f_mr[kk] = aur * aur; f_mz[kk] = auz * auz;
-                f_rz[kk] = aur * duzdz; f_zr[kk] = auz * durdz;
-            };
-            knot(4);
+            // bottom knot: the top knot of the sublayer below when it belongs to the same layer
+            if (s == 0) knot(4);
+            else { f_mr[4] = f_mr[0]; f_mz[4] = f_mz[0]; f_rz[4] = f_rz[0]; f_zr[4] = f_zr[0]; }
 #pragma unroll
             for (int kk = 3; kk >= 0; --kk) {
                 if (do_y) prop_apply(P, y);
@@ -1054,6 +1060,7 @@ __global__ __launch_bounds__(256) void surfdisp_finish_kernel(FinishArgs A)
     for (int pass = 0; pass < 2; ++pass) {
         const float *src = pass ? A.ut : A.ct;
         float *dst = pass ? A.u : A.c;
+        if (!src || !dst) continue;                 // phase-only call: no group velocities (block-uniform)
         for (int i = threadIdx.x; i < 64 * P; i += 256) {
             const int k = i / 64, bl = i % 64;
             if (bl < nb) tile[bl * PS + k] = src[(size_t)k * B + b0 + bl];

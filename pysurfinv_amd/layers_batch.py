@@ -1,0 +1,289 @@
+"""Batched parameters -> layer stack (reference layer L3: ``Model1D.seisPropGrids/Layers``
+``models.py:72-102`` and the layer classes of ``layers.py:139-284``), evaluated for B parameter
+vectors at once with torch ops on the device, so that the Metropolis driver never leaves the GPU.
+
+A *setting* is the reference's own dict (``models.py:42-51``; example ``point.py:373-391``):
+
+    {'Sediment': {'H': 2., 'Vs': [[1.5,'abs',.5,.05], [2.2,'abs',.5,.05]]},
+     'Crust':    {'H': [35.,'abs',10.,1.], 'Vs': [[3.4,'abs',.3,.02], ...]},
+     'Mantle':   {'H': 160., 'Vs': [[4.4,'abs',.4,.02], ...]},
+     'Info':     {'modelType': 'MCInv', 'refLayer': True}}
+
+Random-walk entries are spelled ``[v, vmin, vmax, step]`` or ``[v, 'abs'|'abs_pos'|'rel'|'rel_pos',
+width, step]`` (``layers.py:583-598``); everything else is a constant.  Parameter order = the
+reference's ``MCinv._brownians()`` order (``models.py:240-253``): layers in dict order, keys in dict
+order, list elements in order.
+
+Supported layer types (rules cited per class): Sediment, Crust, Mantle/OceanMantle, OceanWater,
+OceanSediment, OceanCrust, and the ReferenceMantle appended when ``Info.refLayer`` is set
+(``models.py:116,153-154``).  Cascadia-specific classes and ``Gauss``/thermal options are out of
+scope.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .brownian import ParamSpec
+
+H_LOWER = 0.01            # models.py:72 hLowerLimit and models.py:102 h>0.01
+
+
+def _is_brownian_entry(v):
+    if isinstance(v, (list, tuple)):
+        if len(v) >= 2 and isinstance(v[1], str) and v[1] in ("abs", "abs_pos", "rel", "rel_pos"):
+            return True
+        if len(v) == 4 and not isinstance(v[1], str):
+            try:
+                float(v[1]); return True
+            except (TypeError, ValueError):
+                return False
+    return False
+
+
+def _is_fixed_entry(v):
+    return isinstance(v, (list, tuple)) and len(v) >= 2 and isinstance(v[1], str) and v[1] in ("fixed", "total")
+
+
+def bspline_basis(npts, n_basis, deg=None, alpha=2.0):
+    """Basis matrix [n_basis, npts] on z = linspace(0, 1, npts); same knot vector and recursion as
+    the reference's ``BsplBasis`` (``layers.py:4-39``).  It does not depend on the layer thickness:
+    the reference scales its knots with ``z[-1]-z[0]``."""
+    z = np.linspace(0.0, 1.0, npts)
+    if n_basis == 1:
+        return np.ones((1, npts))
+    if n_basis == 2:
+        return np.stack([np.linspace(1, 0, npts), np.linspace(0, 1, npts)])
+    eps = np.finfo(float).eps
+    order = (3 + (n_basis >= 4)) if deg is None else int(deg)
+    n = n_basis
+    x = np.zeros(n + order)
+    x[: order - 1] = -eps
+    x[order - 1] = 0.0
+    x[order:n] = np.power(alpha, np.arange(n - order)) * (alpha - 1) / (np.power(alpha, n - order + 1) - 1)
+    x[n] = 1.0
+    x[n + 1:] = 1.0 + eps
+    ncol = len(x) - 1
+    # order-1 (piecewise constant) functions, then raise the order one at a time (Cox - de Boor)
+    cur = ((z[:, None] >= x[None, :-1]) & (z[:, None] < x[None, 1:])).astype(float)
+    for k in range(1, order):
+        nxt = cur.copy()                                   # columns not recomputed keep their values
+        for i in range(ncol - k):
+            col = np.zeros(npts)
+            d1 = x[i + k] - x[i]
+            d2 = x[i + k + 1] - x[i + 1]
+            if d1 != 0:
+                col += cur[:, i] * (z - x[i]) / d1
+            if d2 != 0:
+                col += cur[:, i + 1] * (x[i + k + 1] - z) / d2
+            nxt[:, i] = col
+        cur = nxt
+    return cur[:, :n].T.copy()
+
+
+def _n_fine_mantle(H):        # Crust / OceanMantle._nFineLayers, layers.py:156-168, 245-257
+    import torch
+    N = torch.full_like(H, 5, dtype=torch.int64)
+    N = torch.where(H > 10, torch.full_like(N, 10), N)
+    N = torch.where(H > 20, torch.full_like(N, 15), N)
+    N = torch.where(H > 60, torch.full_like(N, 30), N)
+    N = torch.where(H >= 150, torch.full_like(N, 60), N)
+    return N
+
+
+class _Slot:
+    """A parameter value that is either a constant or column ``idx`` of the parameter block."""
+    __slots__ = ("const", "idx")
+
+    def __init__(self, const=None, idx=None):
+        self.const, self.idx = const, idx
+
+    def get(self, params):
+        import torch
+        if self.idx is not None:
+            return params[:, self.idx]
+        return torch.full((params.shape[0],), float(self.const), dtype=params.dtype, device=params.device)
+
+
+class Model1DBatch:
+    LAYER_TYPES = {"Sediment": "sed", "Crust": "crust", "Mantle": "mantle", "OceanMantle": "mantle",
+                   "OceanWater": "water", "OceanSediment": "osed", "OceanCrust": "ocrust"}
+
+    def __init__(self, setting: dict, device="cpu"):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+        self.setting = setting
+        self.info = dict(setting.get("Info", {}))
+        entries, names = [], []
+
+        def slot(v, name):
+            if _is_brownian_entry(v):
+                entries.append(list(v)); names.append(name)
+                return _Slot(idx=len(entries) - 1)
+            if _is_fixed_entry(v):
+                return _Slot(const=float(v[0]))
+            return _Slot(const=float(v))
+
+        self.layers = []
+        for key, parm in setting.items():
+            if key == "Info":
+                continue
+            if key not in self.LAYER_TYPES:
+                raise ValueError(f"layer type {key!r} is not supported by Model1DBatch")
+            kind = self.LAYER_TYPES[key]
+            lay = {"kind": kind, "name": key}
+            for k, v in parm.items():                      # dict order = _brownians() order
+                if k in ("H", "BottomDepth"):
+                    lay["Hkey"] = k
+                    lay["H"] = slot(v, f"{key}.{k}")
+                elif k == "Vs":
+                    if isinstance(v, (list, tuple)) and not _is_brownian_entry(v) and not _is_fixed_entry(v):
+                        lay["Vs"] = [slot(e, f"{key}.Vs[{i}]") for i, e in enumerate(v)]
+                    else:
+                        lay["Vs"] = [slot(v, f"{key}.Vs")]
+                        lay["Vs_scalar"] = True
+                elif k == "deg":
+                    lay["deg"] = int(v)
+                elif k in ("Gauss",):
+                    raise ValueError("Crust 'Gauss' option is out of scope")
+            if kind == "water":
+                lay["Vs"] = []
+            self.layers.append(lay)
+        self.spec = ParamSpec.from_entries(entries, names)
+        self._basis = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _bspl(self, N, n_basis, deg):
+        key = (int(N), int(n_basis), deg)
+        if key not in self._basis:
+            self._basis[key] = self.torch.as_tensor(bspline_basis(int(N) + 1, int(n_basis), deg),
+                                                    dtype=self.torch.float64, device=self.device)
+        return self._basis[key]
+
+    def _layer_grid(self, lay, params, z_bottom, N):
+        """Grids (z[Bg,N+1] relative to the layer top, vs, vp, rho, qs, qp) for one layer type."""
+        torch = self.torch
+        Bg = params.shape[0]
+        H = lay["H"].get(params)
+        if lay.get("Hkey") == "BottomDepth":               # layers.py:119-124
+            H = H - z_bottom
+        t = torch.linspace(0.0, 1.0, N + 1, dtype=torch.float64, device=self.device)[None, :]
+        z = t * H[:, None]
+        kind = lay["kind"]
+        ones = torch.ones((Bg, N + 1), dtype=torch.float64, device=self.device)
+        if kind == "water":                                # layers.py:187-199
+            return z, 0 * ones, 1.475 * ones, 1.027 * ones, 10000. * ones, 57822. * ones
+        coef = torch.stack([s.get(params) for s in lay["Vs"]], dim=1)      # [Bg, nb]
+        nb = coef.shape[1]
+        if kind in ("sed", "ocrust"):                      # layers.py:145-149, 218-222
+            vs = coef[:, :1] + (coef[:, 1:2] - coef[:, :1]) * t if nb == 2 else coef[:, :1] * ones
+        elif kind == "osed":                               # layers.py:206-207
+            vs = coef[:, :1] * ones
+        else:                                              # B-spline layers, layers.py:169-172, 258-261
+            vs = coef @ self._bspl(N, nb, lay.get("deg"))
+        if kind == "sed":                                  # layers.py:150-155
+            vp = vs * 2.0
+            rho = 1.22679 + 1.53201 * vs - 0.83668 * vs * vs + 0.20673 * vs ** 3 - 0.01656 * vs ** 4
+            qs, qp = 80. * ones, 160. * ones
+        elif kind == "crust":                              # layers.py:179-184
+            vp = vs * 1.80
+            rho = 1.22679 + 1.53201 * vs - 0.83668 * vs * vs + 0.20673 * vs ** 3 - 0.01656 * vs ** 4
+            qs, qp = 600. * ones, 1400. * ones
+        elif kind == "mantle":                             # layers.py:262-267
+            vp = vs * 1.76
+            rho = 3.4268 + (vs - 4.5) / 4.5
+            qs, qp = 150. * ones, 1400. * ones
+        elif kind == "osed":                               # layers.py:208-213
+            vp = vs * 1.23 + 1.28
+            rho = 0.541 + 0.3601 * vp
+            qs, qp = 80. * ones, 160. * ones
+        elif kind == "ocrust":                             # layers.py:223-228
+            vp = vs * 1.8
+            rho = 0.541 + 0.3601 * vp
+            qs, qp = 350. * ones, 1400. * ones
+        else:
+            raise AssertionError(kind)
+        return z, vs, vp, rho, qs, qp
+
+    def _n_fine(self, lay, params, z_bottom):
+        torch = self.torch
+        H = lay["H"].get(params)
+        if lay.get("Hkey") == "BottomDepth":
+            H = H - z_bottom
+        kind = lay["kind"]
+        if kind in ("sed", "osed", "water"):
+            N = torch.ones_like(H, dtype=torch.int64)
+        elif kind in ("crust", "mantle"):
+            N = _n_fine_mantle(H)
+        else:                                              # OceanCrust, layers.py:216-217
+            N = torch.clamp(torch.round(H / 2).to(torch.int64), 2, 10)
+        return torch.where(H < H_LOWER, torch.full_like(N, -1), N), H     # -1: layer skipped (models.py:80-81)
+
+    # ------------------------------------------------------------------ public
+    def seis_prop_layers(self, params):
+        """(h, vs, vp, rho, qs, qp) float64 [B, Lmax] padded with zeros, and nlay[B] -
+        ``Model1D.seisPropLayers(refLayer=Info.refLayer)`` for every row of ``params``."""
+        torch = self.torch
+        params = params.to(torch.float64)
+        B = params.shape[0]
+        ref_layer = bool(self.info.get("refLayer", False))
+        topo = float(self.info.get("topo", 0.0))
+        z_start = -max(topo, 0.0)                          # models.py:75
+        # pass 1: fine-layer counts (they depend on the thicknesses, hence on the parameters)
+        zb = torch.full((B,), z_start, dtype=torch.float64, device=self.device)
+        sig = []
+        for lay in self.layers:
+            N, H = self._n_fine(lay, params, zb)
+            sig.append(N)
+            zb = torch.where(N >= 0, zb + H, zb)
+        sig = torch.stack(sig, dim=1)                      # [B, nlayers]
+        uniq, inv = torch.unique(sig, dim=0, return_inverse=True)
+        Lcap = int((uniq.clamp(min=0) + 1).sum(dim=1).max().item()) + (21 if ref_layer else 0)
+        out = [torch.zeros((B, Lcap), dtype=torch.float64, device=self.device) for _ in range(6)]
+        nlay = torch.zeros(B, dtype=torch.int32, device=self.device)
+        for g in range(uniq.shape[0]):
+            rows = (inv == g).nonzero(as_tuple=True)[0]
+            p = params[rows]
+            zbot = torch.full((rows.numel(),), z_start, dtype=torch.float64, device=self.device)
+            cols = [[] for _ in range(6)]
+            for li, lay in enumerate(self.layers):
+                N = int(uniq[g, li].item())
+                if N < 0:
+                    continue
+                z, vs, vp, rho, qs, qp = self._layer_grid(lay, p, zbot, N)
+                for c_, a in zip(cols, (z + zbot[:, None], vs, vp, rho, qs, qp)):
+                    c_.append(a)
+                zbot = zbot + z[:, -1]
+            if ref_layer:                                  # ReferenceMantle, layers.py:267-284
+                vs0, vp0, rho0, qs0, qp0 = (cols[i][-1][:, -1:] for i in range(1, 6))
+                t = torch.linspace(0.0, 1.0, 21, dtype=torch.float64, device=self.device)[None, :]
+                zr = t * 300.0
+                vs = vs0 + zr * (0.35 / 200)
+                vp = vp0 + (vs * 1.76 - vs[:, :1] * 1.76)
+                rho = rho0 + ((3.4268 + (vs - 4.5) / 4.5) - (3.4268 + (vs[:, :1] - 4.5) / 4.5))
+                one = torch.ones_like(zr)
+                for c_, a in zip(cols, (zr + zbot[:, None], vs, vp, rho, qs0 * one, qp0 * one)):
+                    c_.append(a)
+            z, vs, vp, rho, qs, qp = (torch.cat(c_, dim=1) for c_ in cols)
+            h = z[:, 1:] - z[:, :-1]                       # models.py:95-101
+            mids = [h] + [(a[:, 1:] + a[:, :-1]) / 2 for a in (vs, vp, rho, qs, qp)]
+            keep = h > H_LOWER
+            order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)
+            n = keep.sum(dim=1)
+            L = h.shape[1]
+            valid = torch.arange(L, device=self.device)[None, :] < n[:, None]
+            for o, a in zip(out, mids):
+                a = torch.gather(a, 1, order) * valid
+                o[rows, :L] = a
+            nlay[rows] = n.to(torch.int32)
+        Lmax = int(nlay.max().item())
+        return tuple(o[:, :Lmax] for o in out), nlay
+
+    def to_model(self, params):
+        """model float32 [B, 5, Lmax] rows (vp, vs, rho, h, 1/Qs) + nlay - what ``_calForward``
+        hands to ``fast_surf`` (models.py:20-27)."""
+        torch = self.torch
+        (h, vs, vp, rho, qs, qp), nlay = self.seis_prop_layers(params)
+        qsinv = torch.where(qs > 0, 1.0 / torch.where(qs > 0, qs, torch.ones_like(qs)), torch.zeros_like(qs))
+        model = torch.stack([vp, vs, rho, h, qsinv], dim=1).to(torch.float32).contiguous()
+        return model, nlay

@@ -1,0 +1,178 @@
+"""Batched, device-resident Metropolis sampler: the GPU counterpart of ``Point.misfit`` /
+``Point.MCinv`` / ``Point.MCinvMP`` (``/root/reference/point.py:15-125``).
+
+The reference advances one chain per process, one forward solve per step.  Here C chains (of one or
+many grid points) advance in lock step: every step is ONE batched forward solve of C stacks through
+``libsurfdisp_hip`` (root-search kernel only - the misfit uses Rayleigh phase velocity,
+``point.py:11,18``), with proposals, misfit and the accept rule evaluated by torch ops on the device.
+
+Semantics kept from the reference:
+* proposal: every random-walk scalar moves by a bounded Gaussian step (``brownian.py:20-27``), the
+  whole proposal is redrawn while ``isgood`` rejects it (<= 1000 times, then uniform ``reset``,
+  ``models.py:192-219``);
+* misfit: ``chi2 = sum(((cO-cP)/uncer)**2)``, ``misfit = sqrt(chi2/N)``, ``chi2 := sqrt(50*chi2)``
+  when ``chi2 >= 50``, ``L = exp(-chi2/2)``; a failed forward solve gives ``(88888, 88888, 0)``
+  (``point.py:20-31``);
+* accept: ``chi1 < chi0`` or ``random() > 1 - exp(-(chi1-chi0)/2)`` (``point.py:34-37``);
+* a chain starts from the initial model (first chain when ``init``) or from a uniform prior draw
+  (``point.py:47-57``); ``mcTrack`` rows are ``[misfit, L, accepted, *params]`` of the PROPOSED
+  model (``models.py:254-256``, ``point.py:58,73-76``); output ``.npz`` keys ``mcTrack, setting,
+  obs, invMeta`` (``point.py:82-85``) so ``PostPoint`` / ``Model3D.loadInvDir`` can read it.
+RNG: CPython's Mersenne Twister cannot be reproduced on the device; the production path uses a
+torch Philox generator (statistical parity), and ``PythonRandomProposer`` replays the reference's
+exact stream for one chain (trace parity, ``tests/test_mcmc.py``).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import _lib
+from .brownian import ParamSpec, TorchProposer
+
+FAIL = 88888.0                                                  # point.py:21
+
+
+class MetropolisBatch:
+    """C chains in lock step.
+
+    to_model(params[C, N] float64 tensor) -> (model[C, 5, L] float32 tensor, nlay[C] int32 or None)
+    isgood(params) -> bool[C] tensor (None: always good, ``MCinv.isgood`` default, models.py:220-224)
+    c_obs, uncer: [P] or [C, P]; entries with uncer <= 0 or NaN c_obs are masked out (the
+    reference uses a masked array, point.py:23-26).
+    """
+
+    def __init__(self, spec: ParamSpec, to_model, periods, c_obs, uncer, device="cuda:0",
+                 isgood=None, proposer=None, seed=None, forward=None):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+        self.spec = spec
+        self.to_model = to_model
+        self.isgood = isgood
+        self.proposer = proposer if proposer is not None else TorchProposer(spec, self.device, seed)
+        self.periods = torch.as_tensor(np.asarray(periods, np.float32), device=self.device)
+        co = torch.as_tensor(np.asarray(c_obs, np.float64), device=self.device)
+        un = torch.as_tensor(np.asarray(uncer, np.float64), device=self.device)
+        self.mask = torch.isfinite(co) & torch.isfinite(un) & (un > 0)
+        self.c_obs = torch.where(self.mask, co, torch.zeros_like(co))
+        self.uncer = torch.where(self.mask, un, torch.ones_like(un))
+        self._plan = None
+        self._forward = forward                                 # test hook: callable(model, nlay) -> (c, status)
+        self.n_forward = 0
+
+    # ------------------------------------------------------------------ forward + misfit
+    def forward_c(self, params):
+        """Rayleigh phase velocities c[C, P] and status[C] for the stacks of ``params``."""
+        torch = self.torch
+        model, nlay = self.to_model(params)
+        self.n_forward += model.shape[0]
+        if self._forward is not None:
+            return self._forward(model, nlay)
+        from .forward import BatchPlan
+        C, _, L = model.shape
+        if self._plan is None or (self._plan.B, self._plan.L) != (C, L):
+            self._plan = BatchPlan(C, L, self.periods.numel(), device=self.device)
+        c, _, st = self._plan.run(model.contiguous(), self.periods, kind=_lib.KIND_RAYLEIGH | _lib.PHASE_ONLY,
+                                  nlay=nlay)
+        return c.to(torch.float64), st
+
+    def misfit(self, params):
+        """(misfit, chiSqr, L) per chain - point.py:15-31."""
+        torch = self.torch
+        cP, st = self.forward_c(params)
+        failed = (st != 0) | (cP < 0.01).any(dim=1)            # models.py:29-33
+        r = torch.where(self.mask, (self.c_obs - cP) / self.uncer, torch.zeros_like(cP))
+        chi = (r * r).sum(dim=1)
+        N = self.mask.sum(dim=-1).to(torch.float64)
+        mis = torch.sqrt(chi / N)
+        chi = torch.where(chi < 50, chi, torch.sqrt(chi * 50.0))
+        L = torch.exp(-0.5 * chi)
+        big = torch.full_like(chi, FAIL)
+        return (torch.where(failed, big, mis), torch.where(failed, big, chi),
+                torch.where(failed, torch.zeros_like(L), L))
+
+    # ------------------------------------------------------------------ proposals
+    def _good(self, p):
+        if self.isgood is None:
+            return self.torch.ones(p.shape[0], dtype=self.torch.bool, device=self.device)
+        return self.isgood(p)
+
+    def perturb(self, p):
+        """MCinv.perturb: redraw the WHOLE proposal while isgood() rejects it (models.py:192-205)."""
+        torch = self.torch
+        new = self.proposer.move(p)
+        bad = ~self._good(new)
+        tries = 1
+        while tries < 1000 and bool(bad.any()):
+            idx = bad.nonzero(as_tuple=True)[0]
+            new = new.clone(); new[idx] = self.proposer.move(p[idx])
+            bad = ~self._good(new)
+            tries += 1
+        if bool(bad.any()):
+            new = torch.where(bad[:, None], self.reset(p.shape[0]), new)
+        return new
+
+    def reset(self, C):
+        """MCinv.reset: uniform prior draw, redrawn while isgood() rejects (models.py:206-219)."""
+        new = self.proposer.reset(C)
+        bad = ~self._good(new)
+        tries = 1
+        while tries < 10000 and bool(bad.any()):
+            idx = bad.nonzero(as_tuple=True)[0]
+            new = new.clone(); new[idx] = self.proposer.reset(idx.numel())
+            bad = ~self._good(new)
+            tries += 1
+        if bool(bad.any()):
+            raise RuntimeError("Error: Cound not find a good model through reset.")   # models.py:219
+        return new
+
+    # ------------------------------------------------------------------ the sampler
+    def run(self, n_chains, chainL, init_first=True, priori=False):
+        """Advance ``n_chains`` chains for ``chainL`` steps each (= MCinvMP with runN = n_chains*chainL).
+
+        Returns mcTrack float64 [n_chains, chainL, 3+N]; chain 0 starts at the initial model when
+        ``init_first`` (point.py:48-51, MCinvMP passes init = (i==0), :97)."""
+        torch = self.torch
+        C, N = int(n_chains), self.spec.n
+        track = torch.zeros((C, chainL, 3 + N), dtype=torch.float64, device=self.device)
+        p0 = self.reset(C) if not (init_first and C == 1) else None
+        if init_first:
+            v0 = torch.as_tensor(self.spec.v0, dtype=torch.float64, device=self.device)[None, :]
+            if not bool(self._good(v0)[0]):
+                v0 = self.perturb(v0)                              # point.py:50-51
+            p0 = v0 if p0 is None else torch.cat([v0, p0[1:]], dim=0)
+        mis0, chi0, L0 = self.misfit(p0)
+        track[:, 0, 0] = mis0; track[:, 0, 1] = L0; track[:, 0, 2] = 1.0; track[:, 0, 3:] = p0
+        for i in range(1, chainL):
+            p1 = self.perturb(p0)
+            if priori:                                             # point.py:66-69
+                track[:, i, 0] = 0.0; track[:, i, 1] = 1.0; track[:, i, 2] = 1.0; track[:, i, 3:] = p1
+                p0 = p1
+                continue
+            mis1, chi1, L1 = self.misfit(p1)
+            better = chi1 < chi0
+            # the reference draws random() only when chi1 >= chi0 (point.py:35-37)
+            u = torch.zeros_like(chi1)
+            need = ~better
+            if bool(need.any()):
+                if C == 1:
+                    u = self.proposer.uniform(1)
+                else:
+                    u = self.proposer.uniform(C)
+            acc = better | (need & (u > 1.0 - torch.exp(-(chi1 - chi0) / 2.0)))
+            track[:, i, 0] = mis1; track[:, i, 1] = L1; track[:, i, 2] = acc.to(torch.float64)
+            track[:, i, 3:] = p1
+            p0 = torch.where(acc[:, None], p1, p0)
+            chi0 = torch.where(acc, chi1, chi0)
+        return track
+
+    # ------------------------------------------------------------------ output (point.py:82-85,120-123)
+    @staticmethod
+    def save_npz(outdir, pid, mc_track, setting, obs, chainL):
+        os.makedirs(outdir, exist_ok=True)
+        mc = np.asarray(mc_track, dtype=np.float64).reshape(-1, np.asarray(mc_track).shape[-1])
+        np.savez_compressed(f"{outdir}/{pid}.npz", mcTrack=mc, setting=dict(setting), obs=obs,
+                            invMeta={"pid": pid, "chainL": chainL})
+        return f"{outdir}/{pid}.npz"

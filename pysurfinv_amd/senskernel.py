@@ -1,0 +1,82 @@
+"""Finite-difference sensitivity kernels: the batched counterpart of ``SensKernelPert``
+(``/root/reference/senskernel.py:129-158``).
+
+The reference calls ``fast_surf`` 2L(+L) times, one perturbed stack at a time: layer i's Vs (or Vp)
+scaled by 0.999 and 1.001, ``kernel[:, i] = (v(1.001) - v(0.999)) / 0.2 / H[i]`` (``:147-150``).
+Here the 2L perturbed stacks (plus the unperturbed one) are ONE batch through the HIP solver.
+
+Differences from the reference, on purpose:
+* ``wtype='L'``: the reference reads ``cr0`` even for Love (``senskernel.py:188-192``, SURVEY.md
+  section 4 defect 7) so its Love kernels are ``None``; here Love uses the Love phase velocities.
+* group-velocity kernels (``ytype='grv'``) come for free from the same batch.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import forward as _forward
+
+GROUP_RULES = {            # sensModel._convert, senskernel.py:104-124
+    "water": lambda vs: (np.full_like(vs, 1.475), np.full_like(vs, 1.027), np.full_like(vs, 10000.)),
+    "sediment": lambda vs: (vs * 1.23 + 1.28, 0.541 + 0.3601 * (vs * 1.23 + 1.28), np.full_like(vs, 80.)),
+    "crust": lambda vs: (vs * 1.8, 0.541 + 0.3601 * (vs * 1.8), np.full_like(vs, 350.)),
+    "mantle": lambda vs: (vs * 1.76, 3.4268 + (vs - 4.5) / 4.5, np.full_like(vs, 150.)),
+}
+
+
+def _derive(vs, grp):
+    vp, rho, qs = np.zeros_like(vs), np.zeros_like(vs), np.zeros_like(vs)
+    for g in set(grp):
+        I = np.array([x == g for x in grp])
+        vp[I], rho[I], qs[I] = GROUP_RULES[g](vs[I])
+    return vp, rho, qs
+
+
+def perturbed_batch(H, Vs, Vp=None, Rho=None, Qs=None, Grp=None, xtype="Vs", lo=0.999, hi=1.001):
+    """model float32 [1+2L', 5, L'] : row 0 unperturbed, rows 1..L' layer i x lo, then x hi
+    (layers with h <= 1e-3 dropped as ``_forward`` does, senskernel.py:182-183)."""
+    H, Vs = np.asarray(H, float), np.asarray(Vs, float)
+    L = H.size
+    stacks = []
+    for scale, i in [(1.0, -1)] + [(lo, i) for i in range(L)] + [(hi, i) for i in range(L)]:
+        vs = Vs.copy()
+        vp = None if Vp is None else np.asarray(Vp, float).copy()
+        if i >= 0:
+            if xtype == "Vs":
+                vs[i] *= scale
+            elif xtype == "Vp":
+                if vp is None:
+                    raise ValueError("xtype='Vp' needs an explicit Vp column (senskernel.py:152)")
+                vp[i] *= scale
+            else:
+                raise ValueError(xtype)
+        if vp is None or Rho is None or Qs is None:
+            dvp, drho, dqs = _derive(vs, Grp)
+        vp_ = vp if vp is not None else dvp
+        rho_ = np.asarray(Rho, float) if Rho is not None else drho
+        qs_ = np.asarray(Qs, float) if Qs is not None else dqs
+        keep = H > 1e-3
+        stacks.append(np.stack([vp_[keep], vs[keep], rho_[keep], H[keep], 1.0 / qs_[keep]]))
+    return np.stack(stacks).astype(np.float32), np.nonzero(H > 1e-3)[0]
+
+
+def sens_kernel_pert(H, Vs, Vp=None, Rho=None, Qs=None, Grp=None, periods=range(20, 101, 10),
+                     wtype="R", xtype="Vs", device=0):
+    """dict(phv=[P, L], grv=[P, L], c0=[P], u0=[P]); NaN columns where a perturbed solve failed."""
+    kind = {"R": 2, "L": 1}[wtype]
+    model, kept = perturbed_batch(H, Vs, Vp, Rho, Qs, Grp, xtype)
+    per = np.asarray(list(periods), np.float32)
+    c, u, st = _forward.forward_batch(model, per, kind=kind, device=device)
+    Lk = kept.size
+    Hk = np.asarray(H, float)[kept]
+    out = {}
+    for name, v in (("phv", c), ("grv", u)):
+        vL, vH = v[1:1 + Lk].astype(np.float64), v[1 + Lk:1 + 2 * Lk].astype(np.float64)
+        k = (vH - vL) / 0.2 / Hk[:, None]                      # senskernel.py:150
+        bad = (st[1:1 + Lk] != 0) | (st[1 + Lk:] != 0)
+        k[bad] = np.nan
+        full = np.zeros((per.size, np.asarray(H).size))
+        full[:, kept] = k.T
+        out[name] = full
+    out["c0"], out["u0"], out["status"] = c[0], u[0], st
+    return out

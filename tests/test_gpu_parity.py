@@ -201,3 +201,39 @@ def test_full_size_properties_config2(hip):
     idx = np.random.default_rng(2).choice(B, 1024, replace=False)
     co, uo, so = cport.forward_batch(model[idx], per, 2, nthreads=8)
     assert relerr(c[idx], co) < TOL_C and relerr(u[idx], uo) < TOL_U
+
+
+def test_extreme_velocities_terminate(hip):
+    """Stacks far outside seismology (Vs x 6: roots above 16 km/s where one fp32 ulp exceeds
+    NEVILL's 1e-6 tolerance) must terminate and still agree with the oracle."""
+    from oracle import cport
+    from pysurfinv_amd import synth
+    model = synth.synth_models(64, 8, seed=9)
+    model[:, 0:2] *= 6.0
+    per = synth.default_periods(12)
+    c, u, st = hip.forward_batch(model, per, 2)
+    co, uo, so = cport.forward_batch(model, per, 2, nthreads=8)
+    rows = ((c > 0) == (co > 0)).all(axis=1)
+    assert rows.mean() > 0.9
+    assert relerr(c[rows], co[rows]) < 1e-4
+
+
+def test_sensitivity_kernels_match_oracle_finite_differences(hip, eus):
+    """SensKernelPert as one batched solve (2L+1 stacks) vs the same finite
+    differences taken with the CPU oracle."""
+    from oracle import cport
+    from pysurfinv_amd import senskernel
+    m = eus["model"][0].astype(np.float64)
+    H, Vs, Vp, Rho, Qs = m[3].copy(), m[1], m[0], m[2], 1.0 / m[4]
+    H[-1] = 50.0
+    periods = list(range(20, 101, 10))
+    k = senskernel.sens_kernel_pert(H, Vs, Vp, Rho, Qs, periods=periods, wtype="R")
+    batch, kept = senskernel.perturbed_batch(H, Vs, Vp, Rho, Qs)
+    co, uo, so = cport.forward_batch(batch, np.asarray(periods, np.float32), 2, nthreads=8)
+    L = kept.size
+    kref = ((co[1 + L:].astype(np.float64) - co[1:1 + L]) / 0.2 / H[kept][:, None]).T
+    assert k["phv"].shape == (len(periods), H.size)
+    scale = np.abs(kref).max()
+    # a kernel is a difference of two c's 0.2 % apart: fp32 noise of ~1e-6 in c is ~1e-3 of the peak
+    assert np.abs(k["phv"] - kref).max() < 5e-3 * scale
+    assert np.nanargmax(np.abs(k["phv"][0])) == np.argmax(np.abs(kref[0]))
