@@ -129,7 +129,7 @@ class MetropolisBatch:
         return new
 
     # ------------------------------------------------------------------ the sampler
-    def run(self, n_chains, chainL, init_first=True, priori=False):
+    def run(self, n_chains, chainL, init_first=True, priori=False, _init_mask=None):
         """Advance ``n_chains`` chains for ``chainL`` steps each (= MCinvMP with runN = n_chains*chainL).
 
         Returns mcTrack float64 [n_chains, chainL, 3+N]; chain 0 starts at the initial model when
@@ -143,6 +143,11 @@ class MetropolisBatch:
             if not bool(self._good(v0)[0]):
                 v0 = self.perturb(v0)                              # point.py:50-51
             p0 = v0 if p0 is None else torch.cat([v0, p0[1:]], dim=0)
+        if _init_mask is not None:                                # several points: chain 0 of each
+            v0 = torch.as_tensor(self.spec.v0, dtype=torch.float64, device=self.device)[None, :]
+            if not bool(self._good(v0)[0]):
+                v0 = self.perturb(v0)
+            p0 = torch.where(_init_mask[:, None], v0.expand_as(p0), p0)
         mis0, chi0, L0 = self.misfit(p0)
         track[:, 0, 0] = mis0; track[:, 0, 1] = L0; track[:, 0, 2] = 1.0; track[:, 0, 3:] = p0
         for i in range(1, chainL):
@@ -167,6 +172,16 @@ class MetropolisBatch:
             p0 = torch.where(acc[:, None], p1, p0)
             chi0 = torch.where(acc, chi1, chi0)
         return track
+
+    def run_points(self, n_points, chains_per_point, chainL):
+        """MCinvMP for n_points at once: chain index = point * chains_per_point + k; chain k = 0 of
+        every point starts at the initial model, the others at prior draws (point.py:95-99).
+        Returns numpy float64 [n_points, chains_per_point, chainL, 3+N]."""
+        torch = self.torch
+        C = n_points * chains_per_point
+        first = (torch.arange(C, device=self.device) % chains_per_point) == 0
+        tr = self.run(C, chainL, init_first=False, _init_mask=first)
+        return tr.reshape(n_points, chains_per_point, chainL, -1).cpu().numpy()
 
     # ------------------------------------------------------------------ output (point.py:82-85,120-123)
     @staticmethod

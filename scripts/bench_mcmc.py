@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Metropolis-driver throughput on one MI355X (BASELINE configs[2] and the per-GPU share of
+configs[3]); prints one JSON line per configuration.  Continental 96-layer model of
+tests/golden/settings.py, 19 periods, Rayleigh-only misfit (point.py:15-31)."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import torch
+from settings import CONT
+from pysurfinv_amd.layers_batch import Model1DBatch
+from pysurfinv_amd.mcmc import MetropolisBatch
+
+G = np.load(os.path.join(ROOT, "tests", "golden", "ref_driver.npz"))
+dev = "cuda:0"
+mb = Model1DBatch(CONT, device=dev)
+for name, chains, steps in (("configs[2] single point: 100 chains (100 000 steps = 100 x 1000)", 100, 60),
+                            ("1 024 chains", 1024, 40),
+                            ("configs[3] per-GPU share: 512 points x 50 chains = 25 600 chains", 25600, 12)):
+    mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], G["trace/c_obs"], G["trace/uncer"], device=dev, seed=0)
+    mc.run(chains, 3); torch.cuda.synchronize()
+    t0 = time.perf_counter(); tr = mc.run(chains, steps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    # split: parameters -> stacks, forward, rest
+    p = mc.reset(chains); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5): m, nl = mb.to_model(p)
+    torch.cuda.synchronize(); t_model = (time.perf_counter() - t1) / 5
+    t1 = time.perf_counter()
+    for _ in range(5): mc.forward_c(p)
+    torch.cuda.synchronize(); t_fwd = (time.perf_counter() - t1) / 5 - t_model
+    print(json.dumps({"config": name, "chains": chains, "steps_timed": steps, "layers": int(nl.max()),
+                      "metropolis_steps_per_s": chains * steps / dt, "ms_per_lockstep": dt / steps * 1e3,
+                      "ms_params_to_stack": t_model * 1e3, "ms_forward_phase_only": t_fwd * 1e3,
+                      "accept_rate": float(tr[:, 1:, 2].mean())}), flush=True)
