@@ -42,6 +42,14 @@ def lib() -> ctypes.CDLL:
         raise SurfdispError(
             f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). pysurfinv_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.  If this library
+    # pulled in /opt/rocm's copy first, a later ``import torch`` would bring up a second runtime that
+    # sees no GPU.  So when torch is installed let it load its runtime first; the dynamic linker then
+    # binds libsurfdisp_hip.so's libamdhip64.so.N dependency to that same copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     fp = ctypes.POINTER(ctypes.c_float)
     ip = ctypes.POINTER(ctypes.c_int)

@@ -246,3 +246,31 @@ def test_sensitivity_kernels_match_oracle_finite_differences(hip, eus):
     thick = H >= 10.0
     scale = np.abs(kref[:, thick]).max()
     assert np.abs(k["phv"][:, thick] - kref[:, thick]).max() < 2e-2 * scale
+
+
+def test_device_entry_is_graph_capturable(hip):
+    """surfdisp_forward_batch_device allocates nothing and never synchronises: the three kernels +
+    finish can be captured in a HIP graph and replayed (launch-bound inner loops of the Metropolis
+    driver)."""
+    import torch
+    from pysurfinv_amd import synth, forward
+    model = torch.from_numpy(synth.synth_models(2048, 10, seed=5)).cuda()
+    per = torch.from_numpy(synth.default_periods(20)).cuda()
+    plan = forward.BatchPlan(2048, 10, 20)
+    c0, u0, _ = plan.run(model, per, kind=2); torch.cuda.synchronize()
+    c0, u0 = c0.clone(), u0.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        plan.run(model, per, kind=2)                       # warm-up on the side stream
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.run(model, per, kind=2)
+    model2 = torch.from_numpy(synth.synth_models(2048, 10, seed=6)).cuda()
+    model.copy_(model2)                                    # new inputs in the captured buffers
+    plan.c.zero_(); plan.u.zero_()
+    g.replay(); torch.cuda.synchronize()
+    from oracle import cport
+    co, uo, _ = cport.forward_batch(model2.cpu().numpy(), per.cpu().numpy(), 2, nthreads=8)
+    assert relerr(plan.c.cpu().numpy(), co) < TOL_C and relerr(plan.u.cpu().numpy(), uo) < TOL_U
+    assert not np.array_equal(plan.c.cpu().numpy(), c0.cpu().numpy())
