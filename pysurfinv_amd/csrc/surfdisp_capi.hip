@@ -58,9 +58,12 @@ int pick_team(int B, int Lmax)
         if (e) G = atoi(e);
     }
     if (G == 0) {
-        // aim for >= 4 wavefronts per SIMD on 256 CUs x 4 SIMDs (262 144 lanes)
-        G = 1;
-        while (G < 64 && (long)B * G < 262144L) G *= 2;
+        // measured on MI355X: large batches want ~4 wavefronts per SIMD
+        // (262 144 lanes on 256 CUs x 4 SIMDs), mid-size ones ~2, tiny ones a whole wavefront per
+        // stack (latency); never fewer than 2 lanes per stack
+        const long target = (B >= 32768) ? 262144L : 131072L;
+        G = 2;
+        while (G < 64 && (long)B * G < target) G *= 2;
     }
     if (G < 1) G = 1;
     if (G > 64) G = 64;

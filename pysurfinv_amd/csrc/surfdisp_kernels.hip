@@ -112,29 +112,41 @@ __global__ __launch_bounds__(256) void surfdisp_prep_kernel(PrepArgs A)
 // per-period, per-layer working values (calcul.f:112-131 then flat1 with n_flat layers)
 struct LayerV { float a, b, rho, d; };
 
-SD_HD __forceinline__ LayerV layer_at(const float *__restrict__ mdl, size_t fs, size_t o,
-                                           float lnT, bool is_halfspace)
+struct LayerRaw { float a_ref, b_ref, rho_ref, qs, dif, qqq, dfl, hsf, hsr; };
+
+SD_HD __forceinline__ LayerRaw layer_load(const float *__restrict__ mdl, size_t fs, size_t o)
+{
+    LayerRaw r;
+    r.a_ref = mdl[F_VP * fs + o];  r.b_ref = mdl[F_VS * fs + o];  r.rho_ref = mdl[F_RHO * fs + o];
+    r.qs = mdl[F_QS * fs + o];     r.dif = mdl[F_DIF * fs + o];   r.qqq = mdl[F_QQQ * fs + o];
+    r.dfl = mdl[F_DFL * fs + o];   r.hsf = mdl[F_HSF * fs + o];   r.hsr = mdl[F_HSR * fs + o];
+    return r;
+}
+
+SD_HD __forceinline__ LayerV layer_derive(const LayerRaw &r, float lnT, bool is_halfspace)
 {
 #pragma clang fp contract(off)   // bit-identical at every call site (K2 integrates twice)
-    const float a_ref = mdl[F_VP * fs + o], b_ref = mdl[F_VS * fs + o];
-    const float rho_ref = mdl[F_RHO * fs + o], qs = mdl[F_QS * fs + o];
-    const float qsq = qs * lnT / PI_REF;                                   // calcul.f:122
-    const float qpq = qsq * 1.33333333f * (b_ref * b_ref) / (a_ref * a_ref); // calcul.f:123
-    float bb = b_ref * (1.0f + qsq);
-    float aa = a_ref * (1.0f + qpq);
+    const float qsq = r.qs * lnT / PI_REF;                                        // calcul.f:122
+    const float qpq = qsq * 1.33333333f * (r.b_ref * r.b_ref) / (r.a_ref * r.a_ref); // calcul.f:123
+    const float bb = r.b_ref * (1.0f + qsq);
+    const float aa = r.a_ref * (1.0f + qpq);
     LayerV v;
     if (!is_halfspace) {
-        const float dif = mdl[F_DIF * fs + o];
-        v.a = aa * dif; v.b = bb * dif;
-        v.rho = rho_ref * mdl[F_QQQ * fs + o];
-        v.d = mdl[F_DFL * fs + o];
+        v.a = aa * r.dif; v.b = bb * r.dif;
+        v.rho = r.rho_ref * r.qqq;
+        v.d = r.dfl;
     } else {
-        const float hsf = mdl[F_HSF * fs + o];
-        v.a = aa * hsf; v.b = bb * hsf;
-        v.rho = rho_ref * mdl[F_HSR * fs + o];
+        v.a = aa * r.hsf; v.b = bb * r.hsf;
+        v.rho = r.rho_ref * r.hsr;
         v.d = 0.0f;
     }
     return v;
+}
+
+SD_HD __forceinline__ LayerV layer_at(const float *__restrict__ mdl, size_t fs, size_t o,
+                                           float lnT, bool is_halfspace)
+{
+    return layer_derive(layer_load(mdl, fs, o), lnT, is_halfspace);
 }
 
 // ================================================================ secular functions (registers)
@@ -204,9 +216,12 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
     const float icsq = 1.0f / csq;
     float b1 = (start == 1) ? 1.0f : 0.0f, b2 = (start == 2) ? 1.0f : 0.0f,
           b3 = (start == 3) ? 1.0f : 0.0f, b4 = 0.0f, b5 = 0.0f;
+    // software pipeline: layer m+1's five LDS values are in flight while layer m is computed
+    float n_sv = W_B(0), n_rho = W_R(0), n_d = W_D(0), n_ia2 = W_IA2(0), n_ib2 = W_IB2(0);
     for (int m = 0; m < mmax - 1; ++m) {
-        const float sv = W_B(m), rho = W_R(m), d = W_D(m);
-        const float arga = fmaf(-csq, W_IA2(m), 1.0f);               // 1 - c^2/a^2, surfa.f:211
+        const float sv = n_sv, rho = n_rho, d = n_d, ia2 = n_ia2, ib2 = n_ib2;
+        n_sv = W_B(m + 1); n_rho = W_R(m + 1); n_d = W_D(m + 1); n_ia2 = W_IA2(m + 1); n_ib2 = W_IB2(m + 1);
+        const float arga = fmaf(-csq, ia2, 1.0f);                    // 1 - c^2/a^2, surfa.f:211
         float ra = sqrt_hw(fabsf(arga));
         if (arga > 0.0f) ra = -ra;
         const float wd = wvno * d;
@@ -232,7 +247,7 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             b1 = n1; b2 = n2; b3 = 0.0f; b4 = 0.0f; b5 = n5;
             continue;
         }
-        const float argb = fmaf(-csq, W_IB2(m), 1.0f);
+        const float argb = fmaf(-csq, ib2, 1.0f);
         float rb = sqrt_hw(fabsf(argb));
         if (argb > 0.0f) rb = -rb;
         const float g = 2.0f * (sv * sv) * icsq;
@@ -299,18 +314,18 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
     }
     // half-space closure, surfa.f:340-354
     const int mh = mmax - 1;
-    const float pp = W_A(mh), sv = W_B(mh), rho = W_R(mh);
-    const float arga = fmaf(-csq, W_IA2(mh), 1.0f);
+    const float pp = W_A(mh), sv = n_sv, rho = n_rho;               // n_* hold layer mmax-1 here
+    const float arga = fmaf(-csq, n_ia2, 1.0f);
     float ra = sqrt_hw(fabsf(arga));
     if (arga > 0.0f) ra = -ra;
-    const float argb = fmaf(-csq, W_IB2(mh), 1.0f);
+    const float argb = fmaf(-csq, n_ib2, 1.0f);
     float rb = sqrt_hw(fabsf(argb));
     if (argb > 0.0f) rb = -rb;
     const float sss = sv * sv, rhp = rho * pp;
     const float g = 2.0f * sss * icsq;
     const float g1 = g - 1.0f;
     const float gra = g * ra, g1s = g1 * g1;
-    const float ira = rcp_nr(ra), igra = rcp_nr(gra), ippp = W_IA2(mh);
+    const float ira = rcp_nr(ra), igra = rcp_nr(gra), ippp = n_ia2;
     const float t12 = rhp * pp, it12 = rcp_nr(t12);
     const float rba = rb - ira;
     const float h11 = -2.0f * rb * sss * ippp + csq * g1s * ippp * igra;
@@ -334,12 +349,16 @@ __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, con
     float h = W_R(mh) * bm * bm;
     float rb = sqrt_hw(fabsf(fmaf(csq, W_IB2(mh), -1.0f)));          // sqrt|c^2/b^2 - 1|
     float ut = 1.0f, tt = h * rb;
+    const int m0 = (mh - 1 > 0) ? mh - 1 : 0;
+    float n_b = W_B(m0), n_d = W_D(m0), n_ib2 = W_IB2(m0), n_r = W_R(m0);
     for (int m = mh - 1; m >= 0; --m) {
-        bm = W_B(m);
+        bm = n_b;
+        const float d = n_d, ib2 = n_ib2, rho = n_r;
+        const int mp = (m > 0) ? m - 1 : 0;                // next layer up, in flight during this one
+        n_b = W_B(mp); n_d = W_D(mp); n_ib2 = W_IB2(mp); n_r = W_R(mp);
         if (bm == 0.0f) continue;                          // water, surfa.f:152
-        const float d = W_D(m);
-        rb = sqrt_hw(fabsf(fmaf(csq, W_IB2(m), -1.0f)));
-        h = W_R(m) * bm * bm;
+        rb = sqrt_hw(fabsf(fmaf(csq, ib2, -1.0f)));
+        h = rho * bm * bm;
         const float ih = rcp_nr(h);
         const float q = -wvno * d * rb;
         float y, z, cosq;
@@ -360,18 +379,23 @@ __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, con
     return -tt;
 }
 
-// layer dropping for one trial velocity, surfa.f:94-105
+// layer dropping for one trial velocity, surfa.f:94-105.  No early exit: every load is independent
+// of the running sum, so the LDS reads pipeline instead of costing one round trip per layer
+// (adding 0.0f for a skipped layer is exact, and nothing after the first crossing can change mm).
 __device__ __forceinline__ int drop_layers(const float *wq, const int Lcap, const int S,
                                            const int n, const float c, const float T)
 {
     const float dmax = FACT * c * T;
     int mm = n;
     float sum = 0.0f;
+    bool found = false;
+#pragma unroll 4
     for (int ii = 0; ii < n; ++ii) {
-        if (c < W_B(ii)) {
-            sum = sum + W_D(ii);
-            if (sum > dmax) { mm = ii + 1; break; }
-        }
+        const float bi = W_B(ii), di = W_D(ii);
+        sum = sum + ((c < bi) ? di : 0.0f);
+        const bool hit = (sum > dmax) && !found;
+        mm = hit ? ii + 1 : mm;
+        found = found || hit;
     }
     return mm < 2 ? 2 : mm;
 }
@@ -612,15 +636,18 @@ SD_HD __forceinline__ Drop drop_group(const float *__restrict__ mdl, size_t fs, 
     const float dmax = FACT * T * c;
     float sum = 0.0f;
     Drop r; r.hs_layer = n - 1; r.nreg_hs = 0;
+    LayerRaw nraw = layer_load(mdl, fs, (size_t)b);
     for (int jl = 0; jl < n; ++jl) {
-        const LayerV v = layer_at(mdl, fs, (size_t)jl * B + b, lnT, jl == n - 1);
+        const LayerRaw raw = nraw;
+        if (jl + 1 < n) nraw = layer_load(mdl, fs, (size_t)(jl + 1) * B + b);
+        const LayerV v = layer_derive(raw, lnT, jl == n - 1);
         if (!(c < v.b)) continue;
         if (jl == n - 1) break;                                   // ii == mmax: keep the true half space
         const int nsub = (jl == 0 && water) ? 1 : ndiv;
         const float dsub = (ndiv > 1 && !(jl == 0 && water)) ? v.d / div : v.d;
         for (int s = 0; s < nsub; ++s) sum = sum + dsub;
         if (!(sum > dmax)) continue;
-        const LayerV nx = layer_at(mdl, fs, (size_t)(jl + 1) * B + b, lnT, jl + 1 == n - 1);
+        const LayerV nx = layer_derive(nraw, lnT, jl + 1 == n - 1);
         bool lower, equal;
         if (KIND == 2) {
             lower = (nx.a < v.a) || (nx.a == v.a && nx.b < v.b);
@@ -753,11 +780,14 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
                                                double xnorm, double bbn, RInt &acc)
 {
 #pragma clang fp contract(off)   // both sweeps must see identical coefficients
+    LayerRaw nraw = layer_load(mdl, fs, (size_t)dr.hs_layer * B + b);
     for (int jl = dr.hs_layer; jl >= 0; --jl) {
+        const LayerRaw raw = nraw;
+        if (jl > 0) nraw = layer_load(mdl, fs, (size_t)(jl - 1) * B + b);   // in flight during this layer
         const int nsub = (jl == 0 && water) ? 1 : ndiv;
         const int nreg = (jl == dr.hs_layer) ? dr.nreg_hs : nsub;
         if (nreg <= 0) continue;
-        const LayerV v = layer_at(mdl, fs, (size_t)jl * B + b, lnT, jl == n - 1);
+        const LayerV v = layer_derive(raw, lnT, jl == n - 1);
         if (v.b <= 0.0f) continue;                                   // water: surfa.f:930
         const float dsub = (ndiv > 1 && !(jl == 0 && water)) ? v.d / div : v.d;
         const float xmu = v.rho * v.b * v.b;                         // surfa.f:831-832
@@ -972,11 +1002,14 @@ SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, i
         float sumi0 = hsv.rho * dm0;
         float sumi1 = hh * dm0;
         bool overflow = false;
+        LayerRaw nraw = layer_load(mdl, fs, (size_t)dr.hs_layer * B + b);
         for (int jl = dr.hs_layer; jl >= 0 && !overflow; --jl) {
+            const LayerRaw raw = nraw;
+            if (jl > 0) nraw = layer_load(mdl, fs, (size_t)(jl - 1) * B + b);
             const int nsub = (jl == 0 && water) ? 1 : ndiv;
             const int nreg = (jl == dr.hs_layer) ? dr.nreg_hs : nsub;
             if (nreg <= 0) continue;
-            const LayerV v = layer_at(mdl, fs, (size_t)jl * B + b, lnT, jl == n - 1);
+            const LayerV v = layer_derive(raw, lnT, jl == n - 1);
             if (v.b == 0.0f) {                                        // surfa.f:524 (still tests |ut|)
                 if (fabsf(ut) > 1.0e10f) overflow = true;
                 continue;

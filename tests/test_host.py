@@ -33,7 +33,8 @@ def test_workspace_and_team_heuristics():
     L.surfdisp_set_team(0)
     os.environ.pop("SURFDISP_TEAM", None)
     assert L.surfdisp_get_team(1, 10) == 64              # one stack: a whole wavefront
-    assert L.surfdisp_get_team(1 << 20, 10) == 1         # huge batch: a lane per stack
+    assert L.surfdisp_get_team(1 << 20, 10) == 2         # huge batch: two lanes per stack
+    assert L.surfdisp_get_team(65536, 10) == 4           # the bench workload
     g = L.surfdisp_get_team(1 << 20, 200)                # LDS bound forces wider teams
     assert g >= 8 and 4 * 200 * (256 // g) * 4 <= 80 * 1024
     assert L.surfdisp_set_team(3) == _lib.ERR_INVALID
