@@ -94,8 +94,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device(f"cuda:{local_rank}"))   # nccl == RCCL on ROCm
+        # nccl == RCCL on ROCm.  BENCH_REHEARSAL=1 (development only): all ranks share cuda:0 and
+        # rendezvous over gloo, to exercise this code path on a one-GPU box.
+        rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+        if rehearsal:
+            local_rank = 0
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     if _lib.lib().surfdisp_device_count() < 1:
