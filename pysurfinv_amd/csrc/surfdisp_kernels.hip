@@ -812,14 +812,11 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
         }
         const float dz = dsub / 4.0f;
         const float l2m = xlamb + 2.0f * xmu;
-        const double ibb = 1.0 / bbn;                 // one fp64 division per layer instead of 4 per knot
         const float ixmu = q.a34, il2m = q.a12;       // 1/mu, 1/(lambda+2mu): already formed above
         float f_mr[5], f_mz[5], f_rz[5], f_zr[5];
         auto knot = [&](int kk) {
-            const float aur = (float)((xnorm * y[0] + z[0]) * ibb);
-            const float auz = (float)((xnorm * y[1] + z[1]) * ibb);
-            const float atz = (float)((xnorm * y[2] + z[2]) * ibb);
-            const float atr = (float)((xnorm * y[3] + z[3]) * ibb);
+            // in this sweep z[] is the combined, normalised solution (xnorm*y + z)/bb itself
+            const float aur = (float)z[0], auz = (float)z[1], atz = (float)z[2], atr = (float)z[3];
             const float durdz = atr * ixmu - wvno * auz;
             const float duzdz = (atz + wvno * xlamb * aur) * il2m;
             f_mr[kk] = aur * aur; f_mz[kk] = auz * auz;
@@ -831,7 +828,6 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
             else { f_mr[4] = f_mr[0]; f_mz[4] = f_mz[0]; f_rz[4] = f_rz[0]; f_zr[4] = f_zr[0]; }
 #pragma unroll
             for (int kk = 3; kk >= 0; --kk) {
-                if (do_y) prop_apply(P, y);
                 prop_apply(P, z);
                 knot(kk);
             }
@@ -943,16 +939,21 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
         }
     }
     if (dbg) { dbg[8] = xnorm; dbg[9] = bbn; }
-    // pass 2: same integration again (bit-identical values), now with the energy integrals
-    for (int i = 0; i < 4; ++i) { y[i] = y0[i]; z[i] = z0[i]; }
+    // sweep 2: integrate the COMBINED solution w = (xnorm*y + z)/bb itself (one 4-vector instead of
+    // two) and accumulate the energy integrals.  The RK4 map is linear, so this equals combining
+    // separately integrated y and z (what the reference does with its stored knots) up to fp64
+    // rounding times the ~1e6 cancellation, i.e. ~1e-10 relative -- invisible after the fp32
+    // rounding of the knot values; it is also what the reference's own refinement pass integrates
+    // (surfa.f:990-998).
+    for (int i = 0; i < 4; ++i) { z[i] = (xnorm * y0[i] + z0[i]) / bbn; y[i] = 0.0; }
     // half-space analytic terms use the combined vector at the top of the half space
-    float aur = (float)((xnorm * y0[0] + z0[0]) / bbn);
-    float auz = (float)((xnorm * y0[1] + z0[1]) / bbn);
+    float aur = (float)z[0];
+    float auz = (float)z[1];
     const bool any_solid = (dr.hs_layer > (wet ? 1 : 0)) || (dr.nreg_hs > 0);
     if (wet && !any_solid) { aur = ratio; auz = 1.0f; }              // label 77777, surfa.f:1140-1144
     (void)tzz;
     rayleigh_sweep<true>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
-                         y, z, true, xnorm, bbn, acc);
+                         y, z, false, xnorm, bbn, acc);
     {   // label 7002, surfa.f:1145-1186
         const float xmu = hsv.rho * hsv.b * hsv.b;
         const float xlamb = hsv.rho * (hsv.a * hsv.a - 2.0f * hsv.b * hsv.b);
