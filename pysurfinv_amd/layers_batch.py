@@ -151,6 +151,42 @@ class Model1DBatch:
             self.layers.append(lay)
         self.spec = ParamSpec.from_entries(entries, names)
         self._basis = {}
+        self._static_sig = self._find_static_signature()
+
+    def _find_static_signature(self):
+        """Fine-layer counts are piecewise constant in the layer thickness.  If no thickness can cross
+        a threshold anywhere inside the prior box, the layer structure is the same for every draw and
+        the per-call signature search (a host synchronisation) is skipped."""
+        import torch
+        lo = torch.as_tensor(self.spec.vmin, dtype=torch.float64)[None, :]
+        hi = torch.as_tensor(self.spec.vmax, dtype=torch.float64)[None, :]
+        topo = float(self.info.get("topo", 0.0))
+        zlo = torch.full((1,), -max(topo, 0.0), dtype=torch.float64)
+        zhi = zlo.clone()
+        sig = []
+        for lay in self.layers:
+            h_lo, h_hi = lay["H"].get(lo), lay["H"].get(hi)
+            if lay.get("Hkey") == "BottomDepth":
+                h_lo, h_hi = h_lo - zhi, h_hi - zlo
+            n_lo, n_hi = self._n_fine_from_H(lay, h_lo), self._n_fine_from_H(lay, h_hi)
+            if int(n_lo) != int(n_hi) or float(h_lo) < H_LOWER * 4:      # also keeps every h > 0.01
+                return None
+            if lay["kind"] not in ("sed", "osed", "water") and float(h_lo) / max(int(n_lo), 1) < H_LOWER * 2:
+                return None
+            sig.append(int(n_lo))
+            zlo, zhi = zlo + h_lo, zhi + h_hi
+        return sig
+
+    def _n_fine_from_H(self, lay, H):
+        torch = self.torch
+        kind = lay["kind"]
+        if kind in ("sed", "osed", "water"):
+            N = torch.ones_like(H, dtype=torch.int64)
+        elif kind in ("crust", "mantle"):
+            N = _n_fine_mantle(H)
+        else:
+            N = torch.clamp(torch.round(H / 2).to(torch.int64), 2, 10)
+        return torch.where(H < H_LOWER, torch.full_like(N, -1), N)
 
     # ------------------------------------------------------------------ helpers
     def _bspl(self, N, n_basis, deg):
@@ -230,21 +266,28 @@ class Model1DBatch:
         topo = float(self.info.get("topo", 0.0))
         z_start = -max(topo, 0.0)                          # models.py:75
         # pass 1: fine-layer counts (they depend on the thicknesses, hence on the parameters)
-        zb = torch.full((B,), z_start, dtype=torch.float64, device=self.device)
-        sig = []
-        for lay in self.layers:
-            N, H = self._n_fine(lay, params, zb)
-            sig.append(N)
-            zb = torch.where(N >= 0, zb + H, zb)
-        sig = torch.stack(sig, dim=1)                      # [B, nlayers]
-        uniq, inv = torch.unique(sig, dim=0, return_inverse=True)
+        static = self._static_sig is not None
+        if static:
+            uniq = torch.as_tensor([self._static_sig], dtype=torch.int64)
+            inv = None
+        else:
+            zb = torch.full((B,), z_start, dtype=torch.float64, device=self.device)
+            sig = []
+            for lay in self.layers:
+                N, H = self._n_fine(lay, params, zb)
+                sig.append(N)
+                zb = torch.where(N >= 0, zb + H, zb)
+            sig = torch.stack(sig, dim=1)                      # [B, nlayers]
+            uniq, inv = torch.unique(sig, dim=0, return_inverse=True)
+            uniq = uniq.cpu()
         Lcap = int((uniq.clamp(min=0) + 1).sum(dim=1).max().item()) + (21 if ref_layer else 0)
         out = [torch.zeros((B, Lcap), dtype=torch.float64, device=self.device) for _ in range(6)]
         nlay = torch.zeros(B, dtype=torch.int32, device=self.device)
         for g in range(uniq.shape[0]):
-            rows = (inv == g).nonzero(as_tuple=True)[0]
+            rows = slice(None) if static else (inv == g).nonzero(as_tuple=True)[0]
             p = params[rows]
-            zbot = torch.full((rows.numel(),), z_start, dtype=torch.float64, device=self.device)
+            nrows = p.shape[0]
+            zbot = torch.full((nrows,), z_start, dtype=torch.float64, device=self.device)
             cols = [[] for _ in range(6)]
             for li, lay in enumerate(self.layers):
                 N = int(uniq[g, li].item())
@@ -276,7 +319,10 @@ class Model1DBatch:
                 a = torch.gather(a, 1, order) * valid
                 o[rows, :L] = a
             nlay[rows] = n.to(torch.int32)
-        Lmax = int(nlay.max().item())
+        # static structure: the interface duplicates are the only rows ever dropped, their number is
+        # known, so the width is known without asking the device
+        Lmax = (Lcap - 1 - (len([n for n in self._static_sig if n >= 0]) - 1 + (1 if ref_layer else 0))
+                if static else int(nlay.max().item()))
         return tuple(o[:, :Lmax] for o in out), nlay
 
     def to_model(self, params):

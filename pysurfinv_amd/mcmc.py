@@ -129,11 +129,22 @@ class MetropolisBatch:
         return new
 
     # ------------------------------------------------------------------ the sampler
-    def run(self, n_chains, chainL, init_first=True, priori=False, _init_mask=None):
+    def run(self, n_chains, chainL, init_first=True, priori=False, _init_mask=None, spec_depth=1):
         """Advance ``n_chains`` chains for ``chainL`` steps each (= MCinvMP with runN = n_chains*chainL).
 
         Returns mcTrack float64 [n_chains, chainL, 3+N]; chain 0 starts at the initial model when
-        ``init_first`` (point.py:48-51, MCinvMP passes init = (i==0), :97)."""
+        ``init_first`` (point.py:48-51, MCinvMP passes init = (i==0), :97).
+
+        spec_depth = d > 1: speculative ("prefetching") Metropolis for small chain counts, where one
+        lock step is latency-bound and the GPU is mostly idle.  The binary tree of the next d
+        accept/reject outcomes is laid out in advance (2^d - 1 proposals per chain, each drawn from
+        the state its branch would be in), all of them go through ONE batched forward solve, and the
+        chain then walks the tree with the usual accept rule: d Metropolis steps per lock step.
+        Every proposal is still drawn from q(current state, .) and tested against the current state,
+        so the chain is distributed exactly as with d = 1; only the order in which random numbers are
+        consumed differs (the exact-replay path of the reference trace uses d = 1)."""
+        if spec_depth > 1 and not priori:
+            return self._run_speculative(n_chains, chainL, init_first, _init_mask, int(spec_depth))
         torch = self.torch
         C, N = int(n_chains), self.spec.n
         track = torch.zeros((C, chainL, 3 + N), dtype=torch.float64, device=self.device)
@@ -171,6 +182,58 @@ class MetropolisBatch:
             track[:, i, 3:] = p1
             p0 = torch.where(acc[:, None], p1, p0)
             chi0 = torch.where(acc, chi1, chi0)
+        return track
+
+    def _start(self, C, init_first, _init_mask):
+        torch = self.torch
+        p0 = self.reset(C) if not (init_first and C == 1) else None
+        if init_first or _init_mask is not None:
+            v0 = torch.as_tensor(self.spec.v0, dtype=torch.float64, device=self.device)[None, :]
+            if not bool(self._good(v0)[0]):
+                v0 = self.perturb(v0)                              # point.py:50-51
+            if _init_mask is not None:
+                p0 = torch.where(_init_mask[:, None], v0.expand_as(p0), p0)
+            else:
+                p0 = v0 if p0 is None else torch.cat([v0, p0[1:]], dim=0)
+        return p0
+
+    def _run_speculative(self, n_chains, chainL, init_first, _init_mask, d):
+        torch = self.torch
+        C, N = int(n_chains), self.spec.n
+        M = (1 << d) - 1                                           # proposals per chain per lock step
+        track = torch.zeros((C, chainL, 3 + N), dtype=torch.float64, device=self.device)
+        p = self._start(C, init_first, _init_mask)
+        mis, chi, L = self.misfit(p)
+        track[:, 0, 0] = mis; track[:, 0, 1] = L; track[:, 0, 2] = 1.0; track[:, 0, 3:] = p
+        ar = torch.arange(C, device=self.device)
+        i = 1
+        while i < chainL:
+            # lay out the tree: node k has children 2k+1 (accepted) and 2k+2 (rejected)
+            S = torch.empty((C, 2 * M + 1, N), dtype=torch.float64, device=self.device)
+            Q = torch.empty((C, M, N), dtype=torch.float64, device=self.device)
+            S[:, 0] = p
+            for lev in range(d):
+                lo, hi = (1 << lev) - 1, (1 << (lev + 1)) - 1
+                st = S[:, lo:hi].reshape(-1, N)
+                q = self.perturb(st).reshape(C, hi - lo, N)
+                Q[:, lo:hi] = q
+                ks = torch.arange(lo, hi, device=self.device)
+                S[:, 2 * ks + 1] = q
+                S[:, 2 * ks + 2] = S[:, lo:hi]
+            misQ, chiQ, LQ = self.misfit(Q.reshape(-1, N))        # ONE forward solve of C*M stacks
+            misQ, chiQ, LQ = misQ.reshape(C, M), chiQ.reshape(C, M), LQ.reshape(C, M)
+            node = torch.zeros(C, dtype=torch.int64, device=self.device)
+            for _ in range(min(d, chainL - i)):
+                chi1, q = chiQ[ar, node], Q[ar, node]
+                better = chi1 < chi
+                u = self.proposer.uniform(C)
+                acc = better | (~better & (u > 1.0 - torch.exp(-(chi1 - chi) / 2.0)))
+                track[:, i, 0] = misQ[ar, node]; track[:, i, 1] = LQ[ar, node]
+                track[:, i, 2] = acc.to(torch.float64); track[:, i, 3:] = q
+                p = torch.where(acc[:, None], q, p)
+                chi = torch.where(acc, chi1, chi)
+                node = torch.where(acc, 2 * node + 1, 2 * node + 2)
+                i += 1
         return track
 
     def run_points(self, n_points, chains_per_point, chainL):

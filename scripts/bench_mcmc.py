@@ -14,12 +14,16 @@ from pysurfinv_amd.mcmc import MetropolisBatch
 G = np.load(os.path.join(ROOT, "tests", "golden", "ref_driver.npz"))
 dev = "cuda:0"
 mb = Model1DBatch(CONT, device=dev)
-for name, chains, steps in (("configs[2] single point: 100 chains (100 000 steps = 100 x 1000)", 100, 60),
-                            ("1 024 chains", 1024, 40),
-                            ("configs[3] per-GPU share: 512 points x 50 chains = 25 600 chains", 25600, 12)):
+for name, chains, steps, depth in (("configs[2] single point: 100 chains (100 000 steps = 100 x 1000)", 100, 61, 1),
+                                   ("configs[2], speculative depth 3", 100, 61, 3),
+                                   ("configs[2], speculative depth 4", 100, 61, 4),
+                                   ("configs[2], speculative depth 5", 100, 61, 5),
+                                   ("1 024 chains", 1024, 41, 1),
+                                   ("1 024 chains, speculative depth 2", 1024, 41, 2),
+                                   ("configs[3] per-GPU share: 512 points x 50 chains = 25 600 chains", 25600, 12, 1)):
     mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], G["trace/c_obs"], G["trace/uncer"], device=dev, seed=0)
-    mc.run(chains, 3); torch.cuda.synchronize()
-    t0 = time.perf_counter(); tr = mc.run(chains, steps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    mc.run(chains, 1 + 2 * depth, spec_depth=depth); torch.cuda.synchronize()
+    t0 = time.perf_counter(); tr = mc.run(chains, steps, spec_depth=depth); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     # split: parameters -> stacks, forward, rest
     p = mc.reset(chains); torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -28,7 +32,7 @@ for name, chains, steps in (("configs[2] single point: 100 chains (100 000 steps
     t1 = time.perf_counter()
     for _ in range(5): mc.forward_c(p)
     torch.cuda.synchronize(); t_fwd = (time.perf_counter() - t1) / 5 - t_model
-    print(json.dumps({"config": name, "chains": chains, "steps_timed": steps, "layers": int(nl.max()),
+    print(json.dumps({"config": name, "chains": chains, "steps_timed": steps, "spec_depth": depth, "layers": int(nl.max()),
                       "metropolis_steps_per_s": chains * steps / dt, "ms_per_lockstep": dt / steps * 1e3,
                       "ms_params_to_stack": t_model * 1e3, "ms_forward_phase_only": t_fwd * 1e3,
                       "accept_rate": float(tr[:, 1:, 2].mean())}), flush=True)

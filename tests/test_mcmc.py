@@ -118,3 +118,26 @@ def test_gpu_sampler_statistics_match_reference_trace():
     assert abs(acc - acc_ref) < 0.15, (acc, acc_ref)
     assert tr[:, :, 0].min() <= ref[:, 0].min() * 1.05
     assert mc.n_forward == 512 * 80
+
+
+def test_speculative_sampler_walks_a_consistent_chain():
+    """spec_depth > 1: rows must form a valid Metropolis chain (each accepted row becomes the state
+    the following proposals are centred on; rejected rows leave it unchanged) and the accept rate
+    must match the plain sampler's."""
+    mb = Model1DBatch(CONT)
+    per = G["trace/periods"].astype(np.float32)
+    kw = dict(device="cpu", forward=oracle_forward(per))
+    mc = MetropolisBatch(mb.spec, mb.to_model, per, G["trace/c_obs"], G["trace/uncer"], seed=4, **kw)
+    tr = mc.run(8, 31, spec_depth=3).numpy()
+    assert tr.shape == (8, 31, 16) and mc.n_forward == 8 + 8 * 7 * 10      # 10 lock steps of 2^3-1 proposals
+    step = np.asarray(mb.spec.step)
+    for c in range(8):
+        state = tr[c, 0, 3:]
+        for i in range(1, 31):
+            prop = tr[c, i, 3:]
+            assert (np.abs(prop - state) < 8 * step).all()          # drawn around the CURRENT state
+            if tr[c, i, 2] == 1:
+                state = prop
+    mc1 = MetropolisBatch(mb.spec, mb.to_model, per, G["trace/c_obs"], G["trace/uncer"], seed=5, **kw)
+    tr1 = mc1.run(8, 31).numpy()
+    assert abs(tr[:, 1:, 2].mean() - tr1[:, 1:, 2].mean()) < 0.2
