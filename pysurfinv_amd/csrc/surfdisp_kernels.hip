@@ -418,6 +418,10 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
     const int b = blockIdx.x * S + slot;
     const int Lcap = A.Lmax, B = A.B, P = A.P;
     float *wq = w_lds + slot;
+    // second slot: a snapshot of the layers the ellipticity recursion of period k still needs while
+    // the main slot already holds period k+1 (only for teams of >= 4 lanes, see OVERLAP below)
+    constexpr bool OVERLAP = (KIND == 2) && (G >= 4);
+    float *wq2 = w_lds + (size_t)NFW * Lcap * S + slot;
     const float *__restrict__ mdl = A.mdl;
     const size_t fs = (size_t)Lcap * B;
 
@@ -434,6 +438,11 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
     bool p0ok = false;                 // p0d was computed with mm_frozen (usable for interpolation)
     bool first = true;
     int status = SURFDISP_OK;
+    // pending ellipticity of the previous period (OVERLAP): evaluated by lanes 0-1 of the first
+    // scan pass of the next period instead of costing a pass of its own
+    bool ell_pend = false;
+    int ell_k = 0, ell_mm = 2;
+    float ell_c = 1.0f, ell_T = 1.0f;
 
     // (re)build the working stack for period k over the first nflat layers only -- the reference
     // refreshes just the layers inside the previous period's effective half space and leaves the
@@ -473,9 +482,15 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         float cj = 1.0f;
         int mmj = 2, start = 1;
         bool eval = (st != ST_DONE);
-        if (st == ST_SCAN) {
+        const float *wl = wq;                                  // the stack this lane's recursion reads
+        float Tl = T;
+        const bool ell_lane = OVERLAP && ell_pend && (st == ST_SCAN) && (j < 2);
+        const int js = (OVERLAP && ell_pend && st == ST_SCAN) ? j - 2 : j;   // scan-lane index in the team
+        if (ell_lane) {
+            cj = ell_c; mmj = ell_mm; start = 2 + j; wl = wq2; Tl = ell_T;
+        } else if (st == ST_SCAN) {
             // exact fp32 grid of the reference: c2 = c1 + dc repeatedly (calcul.f:157,161)
-            const int nadd = first ? j : j + 1;
+            const int nadd = first ? js : js + 1;
             cj = p0c;
 #pragma unroll
             for (int i = 0; i < G; ++i) if (i < nadd) cj = cj + DC;
@@ -490,8 +505,8 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         }
         float val = 0.0f;
         if (eval) {
-            if (KIND == 2) val = delta_rayleigh(wq, Lcap, S, mmj, cj, T, start);
-            else           val = delta_love(wq, Lcap, S, mmj, cj, T);
+            if (KIND == 2) val = delta_rayleigh(wl, Lcap, S, mmj, cj, Tl, start);
+            else           val = delta_love(wl, Lcap, S, mmj, cj, Tl);
         }
         // ---------------------------------------------------------------- team-level decisions
         const int lm1 = (lane + 63) & 63;
@@ -500,8 +515,8 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         const float pd = (j == 0) ? p0d : sv_;
         const int smm = __shfl(mmj, lm1);
         const int pmm = (j == 0) ? p0mm : smm;
-        const bool searching = (st == ST_SCAN) || (st == ST_REFINE);
-        const bool has_prev = !((st == ST_SCAN) && first && (j == 0));
+        const bool searching = ((st == ST_SCAN) || (st == ST_REFINE)) && !ell_lane;
+        const bool has_prev = !((st == ST_SCAN) && first && (js == 0));
         const bool cross = has_prev && (signbit(val) != signbit(pd));
         bool guard = false;
         if (st == ST_SCAN && has_prev && !cross)               // calcul.f:165-166
@@ -525,6 +540,10 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         const float pl_c = __shfl(cj, pl), pl_d = __shfl(val, pl);
 
         bool solved = false, failed = false;
+        if (OVERLAP && ell_pend && st == ST_SCAN) {
+            if (j == 0) A.ratio[(size_t)ell_k * B + b] = 0.5f * v1 / v0;   // surfa.f:363
+            ell_pend = false;
+        }
         if (st == ST_SCAN) {
             ++passes;
             if (fl >= 0 && e_cross) {                          // bracket found -> refine
@@ -576,7 +595,19 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
                 if (!(w > 1.0e-6f) || (!(w > A.wtol) && agree) || passes > 64) {
                     croot = p0c + (inside ? t : ts);
                     if (croot <= W_B(mm_frozen - 1)) {             // calcul.f:191
-                        if (KIND == 2) { st = ST_ELLIP; sub = 0; }
+                        if (KIND == 2) {
+                            if (OVERLAP && k + 1 < P) {
+                                // snapshot the layers the ellipticity recursion reads, then move on:
+                                // the next build overwrites exactly these (first mm_frozen) layers
+                                for (int i = j; i < mm_frozen; i += G) {
+#pragma unroll
+                                    for (int f = 0; f < NFW; ++f)
+                                        wq2[(f * Lcap + i) * S] = wq[(f * Lcap + i) * S];
+                                }
+                                ell_pend = true; ell_k = k; ell_mm = mm_frozen; ell_c = croot; ell_T = T;
+                                solved = true;
+                            } else { st = ST_ELLIP; sub = 0; }
+                        }
                         else solved = true;
                     } else failed = true;
                 }
@@ -593,7 +624,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         if (solved) {
             if (j == 0) {
                 A.c[(size_t)k * B + b] = croot;                // period-major: coalesced across teams
-                if (KIND == 2) A.ratio[(size_t)k * B + b] = r12;
+                if (KIND == 2 && !ell_pend) A.ratio[(size_t)k * B + b] = r12;
             }
             nsolved = ++k;
             if (k >= P) { st = ST_DONE; }
@@ -1117,7 +1148,7 @@ template <int KIND, int G>
 hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 {
     constexpr int S = 256 / G;
-    const size_t lds = (size_t)sd::NFW * a.Lmax * S * sizeof(float);
+    const size_t lds = sd::phase_lds_bytes(a.Lmax, G);
     auto kern = sd::surfdisp_phase_kernel<KIND, G>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1146,7 +1177,9 @@ hipError_t launch_phase_k(hipStream_t s, const sd::PhaseArgs &a, int G)
 
 namespace sd {
 
-size_t phase_lds_bytes(int Lmax, int G) { return (size_t)NFW * Lmax * (256 / G) * sizeof(float); }
+// working stack per team (+ the ellipticity snapshot slot for teams of >= 4 lanes; allocated for
+// Love too so that one number describes a launch)
+size_t phase_lds_bytes(int Lmax, int G) { return (size_t)(G >= 4 ? 2 : 1) * NFW * Lmax * (256 / G) * sizeof(float); }
 
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a)
 {
