@@ -125,3 +125,30 @@ def forward_batch_torch(model, periods, kind=2, nlay=None):
     B, _, L = model.shape
     plan = BatchPlan(B, L, periods.numel(), device=model.device)
     return plan.run(model, periods, kind=kind, nlay=nlay)
+
+
+class JointPlan:
+    """Rayleigh + Love, phase + group velocity of the same stacks (BASELINE configs[4] shape):
+    two BatchPlans on two HIP streams so the Love kernels fill the machine while the Rayleigh
+    root search drains.  Outputs stay on the device: dict(cR, uR, cL, uL, statusR, statusL)."""
+
+    def __init__(self, B, L, P, device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+        self.ray = BatchPlan(B, L, P, device=device)
+        self.love = BatchPlan(B, L, P, device=device)
+        self.s_ray = torch.cuda.Stream(device=self.device)
+        self.s_love = torch.cuda.Stream(device=self.device)
+
+    def run(self, model, periods, nlay=None):
+        torch = self.torch
+        cur = torch.cuda.current_stream(self.device)
+        for s in (self.s_ray, self.s_love):
+            s.wait_stream(cur)                       # inputs were produced on the caller's stream
+        with torch.cuda.stream(self.s_ray):
+            cR, uR, sR = self.ray.run(model, periods, kind=_lib.KIND_RAYLEIGH, nlay=nlay)
+        with torch.cuda.stream(self.s_love):
+            cL, uL, sL = self.love.run(model, periods, kind=_lib.KIND_LOVE, nlay=nlay)
+        cur.wait_stream(self.s_ray); cur.wait_stream(self.s_love)
+        return dict(cR=cR, uR=uR, cL=cL, uL=uL, statusR=sR, statusL=sL)

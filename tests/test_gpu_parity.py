@@ -274,3 +274,17 @@ def test_device_entry_is_graph_capturable(hip):
     co, uo, _ = cport.forward_batch(model2.cpu().numpy(), per.cpu().numpy(), 2, nthreads=8)
     assert relerr(plan.c.cpu().numpy(), co) < TOL_C and relerr(plan.u.cpu().numpy(), uo) < TOL_U
     assert not np.array_equal(plan.c.cpu().numpy(), c0.cpu().numpy())
+
+
+def test_joint_rayleigh_love_two_streams(hip, ref_cases):
+    """BASELINE configs[4] shape: R+L, c+U, 64-layer stacks, both wave types in flight together."""
+    import torch
+    from pysurfinv_amd import forward
+    dR, dL = ref_cases["synth_L64_R"], ref_cases["synth_L64_L"]
+    assert np.array_equal(dR["model"], dL["model"])
+    model = torch.from_numpy(dR["model"]).cuda(); per = torch.from_numpy(dR["periods"]).cuda()
+    plan = forward.JointPlan(model.shape[0], 64, per.numel())
+    out = plan.run(model, per); torch.cuda.synchronize()
+    for w, d in (("R", dR), ("L", dL)):
+        assert relerr(out[f"c{w}"].cpu().numpy(), d["c"]) < TOL_C
+        assert relerr(out[f"u{w}"].cpu().numpy(), d["u"]) < TOL_U
