@@ -288,3 +288,29 @@ def test_joint_rayleigh_love_two_streams(hip, ref_cases):
     for w, d in (("R", dR), ("L", dL)):
         assert relerr(out[f"c{w}"].cpu().numpy(), d["c"]) < TOL_C
         assert relerr(out[f"u{w}"].cpu().numpy(), d["u"]) < TOL_U
+
+
+@pytest.mark.parametrize("B,L,P", [(1, 2, 1), (3, 5, 200), (2, 200, 7), (70000, 4, 3)])
+def test_shape_extremes_against_oracle(hip, B, L, P):
+    """Smallest and largest shapes the ABI accepts (P <= 200 as fast_surf.pyf:14-19, L <= 200)."""
+    from oracle import cport
+    from pysurfinv_amd import synth
+    model = synth.synth_models(B, L, seed=L + P)
+    per = np.linspace(6.0, 150.0, P).astype(np.float32) if P > 1 else np.array([20.0], np.float32)
+    c, u, st = hip.forward_batch(model, per, 2)
+    n = min(B, 256)
+    co, uo, so = cport.forward_batch(model[:n], per, 2, nthreads=8)
+    assert np.array_equal(c[:n] > 0, co > 0)
+    assert relerr(c[:n], co) < TOL_C and relerr(u[:n], uo) < TOL_U
+
+
+def test_unsorted_and_degenerate_periods_terminate(hip):
+    """Descending / repeated / non-positive periods are outside the contract (ascending list), but
+    must come back (zeros or values), never hang."""
+    from pysurfinv_amd import synth
+    model = synth.synth_models(64, 10, seed=1)
+    for per in ([80.0, 40.0, 20.0, 10.0], [20.0, 20.0, 20.0], [0.0, 10.0], [-5.0, 10.0], [np.nan, 10.0]):
+        c, u, st = hip.forward_batch(model, np.asarray(per, np.float32), 2)
+        assert c.shape == (64, len(per))
+        c, u, st = hip.forward_batch(model, np.asarray(per, np.float32), 1)
+        assert c.shape == (64, len(per))
