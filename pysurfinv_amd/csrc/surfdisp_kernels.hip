@@ -150,8 +150,8 @@ SD_HD __forceinline__ LayerV layer_at(const float *__restrict__ mdl, size_t fs, 
 }
 
 // ================================================================ secular functions (registers)
-// LDS working stack of one team: w[(f*Lcap + m)*S + slot], f = 0..3 (a, b, rho, d)
-#define W_A(m) wq[((0 * Lcap + (m)) * S)]
+// LDS working stack of one team: w[(f*Lcap + m)*S + slot], f = 0..5 (1/rho, b, rho, d, 1/a^2, 1/b^2)
+#define W_IR(m) wq[((0 * Lcap + (m)) * S)]    // 1/rho
 #define W_B(m) wq[((1 * Lcap + (m)) * S)]
 #define W_R(m) wq[((2 * Lcap + (m)) * S)]
 #define W_D(m) wq[((3 * Lcap + (m)) * S)]
@@ -182,6 +182,20 @@ __device__ __forceinline__ float exp_sp(float x)
     const float tf = (t - ti) + tl;                          // |tf| <= 0.5 (+eps)
     const float p = __builtin_amdgcn_exp2f(tf);
     return __builtin_amdgcn_ldexpf(p, (int)ti);
+}
+// sinh(x), cosh(x) from one split product: 0.5*e^x = 2^(t-1)*(1 + tl*ln2), 0.5*e^-x likewise
+__device__ __forceinline__ void sinhcosh_sp(float x, float *sh, float *ch)
+{
+    const float L2E_HI = 1.44269502e+00f, L2E_LO = 1.92596299e-08f, LN2 = 6.93147182e-01f;
+    const float t = x * L2E_HI;
+    const float tl = fmaf(x, L2E_LO, fmaf(x, L2E_HI, -t));     // low part of x*log2(e)
+    const float corr = tl * LN2;
+    const float p = __builtin_amdgcn_exp2f(t - 1.0f);
+    const float q = __builtin_amdgcn_exp2f(-t - 1.0f);
+    const float eh = fmaf(p, corr, p);
+    const float emh = fmaf(q, -corr, q);
+    *sh = eh - emh;
+    *ch = eh + emh;
 }
 __device__ __forceinline__ void sincos_cw(float x, float *sn, float *cs)
 {
@@ -217,10 +231,11 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
     float b1 = (start == 1) ? 1.0f : 0.0f, b2 = (start == 2) ? 1.0f : 0.0f,
           b3 = (start == 3) ? 1.0f : 0.0f, b4 = 0.0f, b5 = 0.0f;
     // software pipeline: layer m+1's five LDS values are in flight while layer m is computed
-    float n_sv = W_B(0), n_rho = W_R(0), n_d = W_D(0), n_ia2 = W_IA2(0), n_ib2 = W_IB2(0);
+    float n_sv = W_B(0), n_rho = W_R(0), n_d = W_D(0), n_ia2 = W_IA2(0), n_ib2 = W_IB2(0), n_ir = W_IR(0);
     for (int m = 0; m < mmax - 1; ++m) {
-        const float sv = n_sv, rho = n_rho, d = n_d, ia2 = n_ia2, ib2 = n_ib2;
+        const float sv = n_sv, rho = n_rho, d = n_d, ia2 = n_ia2, ib2 = n_ib2, irho = n_ir;
         n_sv = W_B(m + 1); n_rho = W_R(m + 1); n_d = W_D(m + 1); n_ia2 = W_IA2(m + 1); n_ib2 = W_IB2(m + 1);
+        n_ir = W_IR(m + 1);
         const float arga = fmaf(-csq, ia2, 1.0f);                    // 1 - c^2/a^2, surfa.f:211
         float ra = sqrt_hw(fabsf(arga));
         if (arga > 0.0f) ra = -ra;
@@ -233,9 +248,9 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             float sinpr, cosp;
             if (fabsf(ra) < ACCUR) { sinpr = wd; cosp = 1.0f; }
             else if (ra < 0.0f) {
-                const float ep = exp_sp(pm), em = rcp_nr(ep);
-                sinpr = (ep - em) / (2.0f * ra);
-                cosp = 0.5f * (ep + em);
+                float sh, ch; sinhcosh_sp(pm, &sh, &ch);
+                sinpr = sh / ra;
+                cosp = ch;
             } else {
                 float sn, cs; sincos_cw(pm, &sn, &cs);
                 sinpr = sn / ra; cosp = cs;
@@ -252,16 +267,15 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         if (argb > 0.0f) rb = -rb;
         const float g = 2.0f * (sv * sv) * icsq;
         const float g1 = g - 1.0f;
-        const float irhoc = rcp_nr(rhoc);
+        const float irhoc = irho * icsq;
         const float pm = wd * ra;
         const float qm = wd * rb;
         float rsinp, sinpr, cosp, rsinq, sinqr, cosq;
         if (ra < 0.0f) {                                   // evanescent P, surfa.f:267-269
-            const float ep = exp_sp(pm), em = rcp_nr(ep);
-            const float sh = 0.5f * (ep - em);
+            float sh, ch; sinhcosh_sp(pm, &sh, &ch);
             rsinp = -ra * sh;
             sinpr = sh * rcp_nr(ra);
-            cosp = 0.5f * (ep + em);
+            cosp = ch;
         } else if (ra == 0.0f) {
             rsinp = 0.0f; sinpr = wd; cosp = 1.0f;
         } else {                                           // oscillatory P, surfa.f:271-273
@@ -274,11 +288,10 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             float sn, cs; sincos_cw(qm, &sn, &cs);
             rsinq = rb * sn; sinqr = sn * rcp_nr(rb); cosq = cs;
         } else {
-            const float ep = exp_sp(qm), em = rcp_nr(ep);
-            const float sh = 0.5f * (ep - em);
+            float sh, ch; sinhcosh_sp(qm, &sh, &ch);
             rsinq = -rb * sh;
             sinqr = sh * rcp_nr(rb);
-            cosq = 0.5f * (ep + em);
+            cosq = ch;
         }
         // the fifteen distinct entries, surfa.f:289-320
         const float rr = rsinp * rsinq, ss = sinpr * sinqr, cc = cosp * cosq;
@@ -313,27 +326,26 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         b1 = n1; b2 = n2; b3 = n3; b4 = n4; b5 = n5;
     }
     // half-space closure, surfa.f:340-354
-    const int mh = mmax - 1;
-    const float pp = W_A(mh), sv = n_sv, rho = n_rho;               // n_* hold layer mmax-1 here
-    const float arga = fmaf(-csq, n_ia2, 1.0f);
+    // (a itself is not needed: every occurrence is a^2, available as 1/ia2)
+    const float sv = n_sv, irho = n_ir, ia2 = n_ia2;                 // n_* hold layer mmax-1 here
+    const float arga = fmaf(-csq, ia2, 1.0f);
     float ra = sqrt_hw(fabsf(arga));
     if (arga > 0.0f) ra = -ra;
     const float argb = fmaf(-csq, n_ib2, 1.0f);
     float rb = sqrt_hw(fabsf(argb));
     if (argb > 0.0f) rb = -rb;
-    const float sss = sv * sv, rhp = rho * pp;
+    const float sss = sv * sv;
     const float g = 2.0f * sss * icsq;
     const float g1 = g - 1.0f;
     const float gra = g * ra, g1s = g1 * g1;
-    const float ira = rcp_nr(ra), igra = rcp_nr(gra), ippp = n_ia2;
-    const float t12 = rhp * pp, it12 = rcp_nr(t12);
+    const float ira = rcp_nr(ra), igra = rcp_nr(gra), ig = rcp_nr(g);
+    const float it12 = ia2 * irho;                                   // 1/(rho a^2)
     const float rba = rb - ira;
-    const float h11 = -2.0f * rb * sss * ippp + csq * g1s * ippp * igra;
+    const float h11 = -2.0f * rb * sss * ia2 + csq * g1s * ia2 * igra;
     const float h13 = -rb * it12 + g1 * it12 * igra;
     const float h14 = rb * it12 * igra;
-    const float irhp = rcp_nr(rhp);
-    const float h15 = rba * irhp * irhp * icsq * rcp_nr(g);
-    const float h12 = -rcp_nr(g) * it12;
+    const float h15 = rba * (irho * irho) * ia2 * icsq * ig;         // rba/(rho a)^2/c^2/g
+    const float h12 = -ig * it12;
     const float bb1 = h11 * b1 + h12 * b2 + 2.0f * h13 * b3 + h14 * b4 + h15 * b5;
     return (start == 1) ? -bb1 : bb1;
 }
@@ -364,10 +376,10 @@ __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, con
         float y, z, cosq;
         if (rb < 0.1e-20f || c == bm) { y = -wvno * d; z = 0.0f; cosq = 1.0f; }
         else if (c < bm) {
-            const float ep = exp_sp(q), em = rcp_nr(ep);
-            y = (ep - em) * (0.5f * rcp_nr(rb));
+            float sh, ch; sinhcosh_sp(q, &sh, &ch);
+            y = sh * rcp_nr(rb);
             z = -rb * rb * y;
-            cosq = (ep + em) * 0.5f;
+            cosq = ch;
         } else {
             float sn, cs; sincos_cw(q, &sn, &cs);
             y = sn * rcp_nr(rb); z = rb * sn; cosq = cs;
@@ -451,7 +463,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         const float lnT = logf(1.0f / T);                      // alog(t_base/t1), calcul.f:122
         for (int i = j; i < nflat; i += G) {
             const LayerV v = layer_at(mdl, fs, (size_t)i * B + b, lnT, i == nflat - 1);
-            W_A(i) = v.a; W_B(i) = v.b; W_R(i) = v.rho; W_D(i) = v.d;
+            W_IR(i) = 1.0f / v.rho; W_B(i) = v.b; W_R(i) = v.rho; W_D(i) = v.d;
             W_IA2(i) = 1.0f / (v.a * v.a);
             W_IB2(i) = (v.b > 0.0f) ? 1.0f / (v.b * v.b) : 0.0f;
         }
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
     if (st != ST_DONE) {
         T = A.per[0];
         // clear the slot (a new process sees zeroed COMMON /d/)
-        for (int i = j; i < Lcap; i += G) { W_A(i) = 0.0f; W_B(i) = 0.0f; W_R(i) = 0.0f; W_D(i) = 0.0f; W_IA2(i) = 0.0f; W_IB2(i) = 0.0f; }
+        for (int i = j; i < Lcap; i += G) { W_IR(i) = 0.0f; W_B(i) = 0.0f; W_R(i) = 0.0f; W_D(i) = 0.0f; W_IA2(i) = 0.0f; W_IB2(i) = 0.0f; }
         build(n);
         b1top = W_B(0);
         // first guess, fast_surf.f:157-171
