@@ -166,11 +166,13 @@ def main():
         value = total_solves / elapsed
         phase_s = kms[1] * 1e-3
         achieved = ALG_BYTES_PER_SOLVE * B_PER_GPU / phase_s / 1e9
-        traffic = None
+        traffic, valu = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("phase_kernel_hbm_bytes_per_launch")
+                tj = json.load(open(tfile))
+                traffic = tj.get("phase_kernel_hbm_bytes_per_launch")
+                valu = tj.get("valu", {}).get("surfdisp_phase_kernel")
             except Exception:
                 traffic = None
         line = {
@@ -191,8 +193,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "surfdisp_phase_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
+                         "valu_pmc": valu,
                          "note": "algorithmic bytes = 360 B/solve x 65536 solves per launch; the path is "
-                                 "VALU/transcendental-bound, not HBM-bound (SURVEY.md 8(d))"},
+                                 "VALU/transcendental-bound, not HBM-bound (SURVEY.md 8(d)); traffic and "
+                                 "valu_pmc come from the committed rocprofv3 --pmc passes (profiles/)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(per_np)
