@@ -36,6 +36,7 @@ constexpr float PI_REF  = 3.1415927f;    // calcul.f:32, fast_surf.f:77
 constexpr float DC      = 0.01f;         // init.f:25
 constexpr float FACT    = 4.0f;          // init.f:25
 constexpr float ACCUR   = 1.e-8f;        // surfa.f:191-192
+constexpr float CLUSTER_DC = 1.0e-4f;    // spacing of clustered refine points (teams of <= 4 lanes)
 
 // SoA field ids of mdl[NF][Lmax][B]
 enum { F_VP = 0, F_VS, F_RHO, F_H, F_QS, F_DIF, F_QQQ, F_DFL, F_HSF, F_HSR, NF = 10 };
@@ -508,7 +509,19 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
             for (int i = 0; i < G; ++i) if (i < nadd) cj = cj + DC;
             mmj = drop_layers(wq, Lcap, S, n, cj, T);          // idrop=0 before every scan trial
         } else if (st == ST_REFINE) {
-            cj = p0c + (float)(j + 1) * ((cb - p0c) / (float)(G + 1));
+            const float w = cb - p0c;
+            cj = p0c + (float)(j + 1) * (w / (float)(G + 1));
+            if (G <= 4 && G > 1 && p0ok && w > 8.0f * CLUSTER_DC) {
+                // small teams: instead of G equidistant points, cluster them around the secant
+                // estimate (spacing CLUSTER_DC).  Delta(c) is smooth across a 0.01 bracket, so the
+                // root normally falls between two neighbours and the next acceptance test passes
+                // (one refine pass instead of two); if it does not, the sign pattern still shrinks
+                // the bracket and the next pass clusters around a better estimate.
+                float ts = -p0d * w / (db - p0d);
+                const float half = 0.5f * (float)(G - 1) * CLUSTER_DC;
+                ts = fminf(fmaxf(ts, half + CLUSTER_DC), w - half - CLUSTER_DC);
+                if (ts == ts) cj = p0c + (ts - half + (float)j * CLUSTER_DC);
+            }
             mmj = mm_frozen;                                   // frozen as NEVILL sees it
         } else if (st == ST_ELLIP) {
             cj = croot; mmj = mm_frozen;
