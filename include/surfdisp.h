@@ -37,6 +37,13 @@ extern "C" {
 
 #define SURFDISP_KIND_LOVE     1   /* == reference kind0 / ilvry */
 #define SURFDISP_KIND_RAYLEIGH 2
+#define SURFDISP_INDEPENDENT   0x20 /* OR into `kind`: one team per (stack, period) root search, every
+                                     * period started from the first-period rule (fast_surf.f:157-171) on
+                                     * a freshly built stack.  P x more parallelism / P x lower latency
+                                     * for small batches; equals the default "faithful" mode to ~1e-6 on
+                                     * monotone stacks but NOT on rough ones (low-velocity zones), where
+                                     * the reference's sequential start rule picks roots and failures
+                                     * (SURVEY.md section 4 defects 2, 9).  Caller opts in. */
 #define SURFDISP_PHASE_ONLY    0x10 /* OR into `kind` of the batched entries: phase velocities only
                                      * (what Point.misfit consumes, point.py:18); u is not written
                                      * and may be NULL */

@@ -15,6 +15,7 @@ SUCCESS, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_WORKSPACE = 0, -1, -2, -3, -4
 OK, PARTIAL, NOROOT, BADMODEL = 0, 1, 2, 4
 KIND_LOVE, KIND_RAYLEIGH = 1, 2
 PHASE_ONLY = 0x10
+INDEPENDENT = 0x20
 NPER_MAX, NLAY_MAX = 200, 200
 
 # every symbol include/surfdisp.h declares

@@ -78,7 +78,7 @@ int pick_team(int B, int Lmax)
 int check_args(int B, int Lmax, int P, int kind, const void *model, const void *per,
                const void *c, const void *u)
 {
-    const int wave = kind & ~SURFDISP_PHASE_ONLY;
+    const int wave = kind & ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT);
     if (B < 1 || Lmax < 2 || Lmax > SURFDISP_NLAY_MAX || P < 1 || P > SURFDISP_NPER_MAX ||
         (wave != SURFDISP_KIND_LOVE && wave != SURFDISP_KIND_RAYLEIGH) || !model || !per || !c ||
         (!u && !(kind & SURFDISP_PHASE_ONLY))) {
@@ -149,11 +149,14 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool phase_only = (kind & SURFDISP_PHASE_ONLY) != 0;
-    kind &= ~SURFDISP_PHASE_ONLY;
+    const bool indep = (kind & SURFDISP_INDEPENDENT) != 0;
+    kind &= ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT);
     const Carve w = carve(workspace, B, Lmax, P);
-    const int G = pick_team(B, Lmax);
+    // independent mode has B*P root searches in flight: size the teams for that many
+    const long units = indep ? (long)B * P : (long)B;
+    const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax);
 
-    sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl};
+    sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl, P, indep ? w.nsolved : nullptr};
     if (ev) SD_HIP(hipEventRecord(ev[0], s));
     SD_HIP(sd::launch_prep(s, kind, pa));
     if (ev) SD_HIP(hipEventRecord(ev[1], s));
@@ -161,11 +164,12 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     if (const char *e = getenv("SURFDISP_WTOL")) wtol = (float)atof(e);
     if (const char *e = getenv("SURFDISP_ATOL")) atol = (float)atof(e);
     sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, status, wtol, atol};
-    SD_HIP(sd::launch_phase(s, kind, G, ph));
+    SD_HIP(sd::launch_phase(s, kind, G, indep, ph));
     if (ev) SD_HIP(hipEventRecord(ev[2], s));
     sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, g_dbg};
     if (!phase_only) SD_HIP(sd::launch_group(s, kind, ga));
-    sd::FinishArgs fa{B, P, w.ct, phase_only ? nullptr : w.ut, c, phase_only ? nullptr : u};
+    sd::FinishArgs fa{B, P, w.ct, phase_only ? nullptr : w.ut, c, phase_only ? nullptr : u,
+                      indep ? w.nsolved : nullptr, w.nl, status};
     SD_HIP(sd::launch_finish(s, fa));
     if (ev) SD_HIP(hipEventRecord(ev[3], s));
     return SURFDISP_SUCCESS;

@@ -13,6 +13,8 @@ struct PrepArgs {
     const float *model;   // [B][5][Lmax] (vp, vs, rho, h, qsinv) as handed over by the caller
     float *mdl;           // [10][Lmax][B] SoA: the five inputs + five flattening factors
     int *nl;              // [B] validated layer count, 0 = bad model
+    int P;
+    int *nsolved_init;    // nullptr, or [B]: set to P (independent mode reduces it with atomicMin)
 };
 
 struct PhaseArgs {
@@ -44,12 +46,15 @@ struct FinishArgs {
     int B, P;
     const float *ct, *ut; // [P][B]
     float *c, *u;         // [B][P] caller's arrays
+    const int *nsolved;   // nullptr (faithful) or [B] first failing period (independent mode)
+    const int *nl;
+    int *status;
 };
 
 size_t phase_lds_bytes(int Lmax, int G);
 hipError_t launch_finish(hipStream_t s, const FinishArgs &a);
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a);
-hipError_t launch_phase(hipStream_t s, int kind, int G, const PhaseArgs &a);
+hipError_t launch_phase(hipStream_t s, int kind, int G, bool independent, const PhaseArgs &a);
 hipError_t launch_group(hipStream_t s, int kind, const GroupArgs &a);
 
 }  // namespace sd

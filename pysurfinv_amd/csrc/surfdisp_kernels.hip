@@ -101,6 +101,7 @@ SD_HD inline void prep_stack(const PrepArgs &A, const int b)
         }
     }
     A.nl[b] = ok ? n : 0;          // 0 => BADMODEL: K1/K2 write zeros
+    if (A.nsolved_init) A.nsolved_init[b] = ok ? A.P : 0;      // independent mode: reduced with atomicMin
 }
 
 template <int KIND>
@@ -416,7 +417,14 @@ __device__ __forceinline__ int drop_layers(const float *wq, const int Lcap, cons
 // ================================================================================== K1: phase
 enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3 };
 
-template <int KIND, int G>
+// INDEP = false: "faithful" - a team owns a stack and walks its periods in order (reference
+//   semantics: start rule 0.9*c(k-1), mmax carry-over, failure cascade).
+// INDEP = true : "independent" - a team owns ONE (stack, period) root search (BASELINE north_star's
+//   work unit): every period starts from the k=1 rule of fast_surf.f:157-171 evaluated at its own
+//   period, on a freshly built full stack.  P times more teams, P times shorter dependency chain:
+//   the mode for small batches; equal to the faithful mode to ~1e-6 on well-behaved (monotone)
+//   stacks, NOT on rough ones (defects 2 and 9) - the caller opts in.
+template <int KIND, int G, bool INDEP>
 __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
 {
     extern __shared__ float w_lds[];
@@ -428,21 +436,24 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
     const int tbase = lane - j;                // first lane of my team within the wavefront
     const unsigned long long tmask =
         (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << tbase);
-    const int b = blockIdx.x * S + slot;
     const int Lcap = A.Lmax, B = A.B, P = A.P;
+    const long tg = (long)blockIdx.x * S + slot;           // team index
+    const int b = INDEP ? (int)(tg % B) : (int)tg;         // consecutive teams = consecutive stacks
+    const int k_own = INDEP ? (int)(tg / B) : 0;           // INDEP: the one period this team solves
+    const bool team_valid = INDEP ? (tg < (long)B * P) : (tg < B);
     float *wq = w_lds + slot;
     // second slot: a snapshot of the layers the ellipticity recursion of period k still needs while
     // the main slot already holds period k+1 (only for teams of >= 4 lanes, see OVERLAP below)
-    constexpr bool OVERLAP = (KIND == 2) && (G >= 4);
+    constexpr bool OVERLAP = (KIND == 2) && (G >= 4) && !INDEP;
     float *wq2 = w_lds + (size_t)NFW * Lcap * S + slot;
     const float *__restrict__ mdl = A.mdl;
     const size_t fs = (size_t)Lcap * B;
 
     int n = 0, st = ST_DONE;
-    if (b < B) { n = A.nl[b]; if (n >= 2) st = ST_SCAN; }
+    if (team_valid) { n = A.nl[b]; if (n >= 2) st = ST_SCAN; }
 
     // team-uniform state
-    int k = 0, nsolved = 0, mm_carry = n, mm_frozen = n, sub = 0, passes = 0;
+    int k = k_own, nsolved = 0, mm_carry = n, mm_frozen = n, sub = 0, passes = 0;
     float T = 1.0f, b1top = 0.0f;
     float p0c = 0.0f, p0d = 0.0f;      // "previous point" of lane 0: scan carry or bracket low end
     float cb = 0.0f, db = 0.0f;        // bracket high end (refine)
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
     };
 
     if (st != ST_DONE) {
-        T = A.per[0];
+        T = A.per[k];
         // clear the slot (a new process sees zeroed COMMON /d/)
         for (int i = j; i < Lcap; i += G) { W_IR(i) = 0.0f; W_B(i) = 0.0f; W_R(i) = 0.0f; W_D(i) = 0.0f; W_IA2(i) = 0.0f; W_IB2(i) = 0.0f; }
         build(n);
@@ -652,7 +663,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
                 if (KIND == 2 && !ell_pend) A.ratio[(size_t)k * B + b] = r12;
             }
             nsolved = ++k;
-            if (k >= P) { st = ST_DONE; }
+            if (INDEP || k >= P) { st = ST_DONE; }
             else {
                 T = A.per[k];
                 mm_carry = mm_frozen;                          // mmax left by the last idrop=0 trial
@@ -668,7 +679,16 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
             st = ST_DONE;
         }
     }
-    if (b < B && j == 0) {
+    if (INDEP) {
+        // a failed period zeroes itself and every later one (calcul.f:203-219): the first failing
+        // period index is reduced over the stack's teams; the finish kernel applies it
+        if (team_valid && j == 0 && n >= 2 && status != SURFDISP_OK) {
+            A.c[(size_t)k_own * B + b] = 0.0f;
+            atomicMin(&A.nsolved[b], k_own);
+        }
+        return;
+    }
+    if (team_valid && j == 0) {
         if (n < 2) status = SURFDISP_BADMODEL;
         for (int q = nsolved; q < P; ++q) A.c[(size_t)q * B + b] = 0.0f;
         A.nsolved[b] = nsolved;
@@ -1147,13 +1167,23 @@ __global__ __launch_bounds__(256) void surfdisp_finish_kernel(FinishArgs A)
     const int B = A.B, P = A.P, PS = P + 1;
     const int b0 = blockIdx.x * 64;
     const int nb = min(64, B - b0);
+    if (A.nsolved && threadIdx.x < nb) {
+        // independent mode: status word from the reduced first-failing period
+        const int bb = b0 + threadIdx.x;
+        const int ns = A.nsolved[bb];
+        if (A.status) A.status[bb] = (A.nl[bb] < 2) ? SURFDISP_BADMODEL : (ns >= P ? SURFDISP_OK : (ns == 0 ? SURFDISP_NOROOT : SURFDISP_PARTIAL));
+    }
     for (int pass = 0; pass < 2; ++pass) {
         const float *src = pass ? A.ut : A.ct;
         float *dst = pass ? A.u : A.c;
         if (!src || !dst) continue;                 // phase-only call: no group velocities (block-uniform)
         for (int i = threadIdx.x; i < 64 * P; i += 256) {
             const int k = i / 64, bl = i % 64;
-            if (bl < nb) tile[bl * PS + k] = src[(size_t)k * B + b0 + bl];
+            if (bl < nb) {
+                float v = src[(size_t)k * B + b0 + bl];
+                if (A.nsolved && k >= A.nsolved[b0 + bl]) v = 0.0f;   // independent mode: failure cascade
+                tile[bl * PS + k] = v;
+            }
         }
         __syncthreads();
         for (int i = threadIdx.x; i < nb * P; i += 256) {
@@ -1169,31 +1199,32 @@ __global__ __launch_bounds__(256) void surfdisp_finish_kernel(FinishArgs A)
 // ======================================================================================= launch
 namespace {
 
-template <int KIND, int G>
+template <int KIND, int G, bool INDEP>
 hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 {
     constexpr int S = 256 / G;
     const size_t lds = sd::phase_lds_bytes(a.Lmax, G);
-    auto kern = sd::surfdisp_phase_kernel<KIND, G>;
+    auto kern = sd::surfdisp_phase_kernel<KIND, G, INDEP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const int grid = (a.B + S - 1) / S;
+    const long teams = INDEP ? (long)a.B * a.P : (long)a.B;
+    const int grid = (int)((teams + S - 1) / S);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
-template <int KIND>
+template <int KIND, bool INDEP>
 hipError_t launch_phase_k(hipStream_t s, const sd::PhaseArgs &a, int G)
 {
     switch (G) {
-        case 1:  return launch_phase_g<KIND, 1>(s, a);
-        case 2:  return launch_phase_g<KIND, 2>(s, a);
-        case 4:  return launch_phase_g<KIND, 4>(s, a);
-        case 8:  return launch_phase_g<KIND, 8>(s, a);
-        case 16: return launch_phase_g<KIND, 16>(s, a);
-        case 32: return launch_phase_g<KIND, 32>(s, a);
-        case 64: return launch_phase_g<KIND, 64>(s, a);
+        case 1:  return launch_phase_g<KIND, 1, INDEP>(s, a);
+        case 2:  return launch_phase_g<KIND, 2, INDEP>(s, a);
+        case 4:  return launch_phase_g<KIND, 4, INDEP>(s, a);
+        case 8:  return launch_phase_g<KIND, 8, INDEP>(s, a);
+        case 16: return launch_phase_g<KIND, 16, INDEP>(s, a);
+        case 32: return launch_phase_g<KIND, 32, INDEP>(s, a);
+        case 64: return launch_phase_g<KIND, 64, INDEP>(s, a);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1214,9 +1245,10 @@ hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a)
     return hipGetLastError();
 }
 
-hipError_t launch_phase(hipStream_t s, int kind, int G, const PhaseArgs &a)
+hipError_t launch_phase(hipStream_t s, int kind, int G, bool independent, const PhaseArgs &a)
 {
-    return kind == 2 ? launch_phase_k<2>(s, a, G) : launch_phase_k<1>(s, a, G);
+    if (independent) return kind == 2 ? launch_phase_k<2, true>(s, a, G) : launch_phase_k<1, true>(s, a, G);
+    return kind == 2 ? launch_phase_k<2, false>(s, a, G) : launch_phase_k<1, false>(s, a, G);
 }
 
 hipError_t launch_finish(hipStream_t s, const FinishArgs &a)

@@ -41,10 +41,13 @@ def _calForward(inProfile, wavetype="Ray", periods=(5, 10, 20, 40, 60, 80), debu
     return cr0[:nper]
 
 
-def forward_batch(model, periods, kind=2, nlay=None, device=0):
+def forward_batch(model, periods, kind=2, nlay=None, device=0, independent=False):
     """model float32 [B,5,L] rows (vp, vs, rho, h, qsinv) -> (c[B,P], u[B,P], status[B]).
 
-    Host buffers in, host buffers out (C ABI surfdisp_forward_batch)."""
+    Host buffers in, host buffers out (C ABI surfdisp_forward_batch).  ``independent=True`` ORs
+    SURFDISP_INDEPENDENT into ``kind`` (one team per (stack, period); see include/surfdisp.h)."""
+    if independent:
+        kind = int(kind) | _lib.INDEPENDENT
     L = _lib.lib()
     model = np.ascontiguousarray(model, dtype=np.float32)
     if model.ndim != 3 or model.shape[1] != 5:
@@ -88,13 +91,15 @@ class BatchPlan:
         self.u = torch.zeros(self.B, self.P, dtype=torch.float32, device=self.device)
         self.status = torch.zeros(self.B, dtype=torch.int32, device=self.device)
 
-    def run_timed(self, model, periods, kind=2, nlay=None):
+    def run_timed(self, model, periods, kind=2, nlay=None, independent=False):
         """As run(), but blocks and also returns the (prep, phase, group) kernel durations in ms,
         measured with HIP events on the launch stream (surfdisp_forward_batch_device_timed)."""
-        return self.run(model, periods, kind=kind, nlay=nlay, _timed=True)
+        return self.run(model, periods, kind=kind, nlay=nlay, _timed=True, independent=independent)
 
-    def run(self, model, periods, kind=2, nlay=None, _timed=False):
+    def run(self, model, periods, kind=2, nlay=None, _timed=False, independent=False):
         torch = self.torch
+        if independent:
+            kind = int(kind) | _lib.INDEPENDENT
         for t, shape in ((model, (self.B, 5, self.L)), (periods, (self.P,))):
             if (t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shape
                     or t.device != self.device):

@@ -44,7 +44,7 @@ class MetropolisBatch:
     """
 
     def __init__(self, spec: ParamSpec, to_model, periods, c_obs, uncer, device="cuda:0",
-                 isgood=None, proposer=None, seed=None, forward=None):
+                 isgood=None, proposer=None, seed=None, forward=None, independent=False):
         import torch
         self.torch = torch
         self.device = torch.device(device)
@@ -60,6 +60,9 @@ class MetropolisBatch:
         self.uncer = torch.where(self.mask, un, torch.ones_like(un))
         self._plan = None
         self._forward = forward                                 # test hook: callable(model, nlay) -> (c, status)
+        # independent=True: period-parallel root search (SURFDISP_INDEPENDENT) - lower latency for few
+        # chains; only for smooth parameterisations (no low-velocity roughness), see include/surfdisp.h
+        self.independent = bool(independent)
         self.n_forward = 0
 
     # ------------------------------------------------------------------ forward + misfit
@@ -75,7 +78,7 @@ class MetropolisBatch:
         if self._plan is None or (self._plan.B, self._plan.L) != (C, L):
             self._plan = BatchPlan(C, L, self.periods.numel(), device=self.device)
         c, _, st = self._plan.run(model.contiguous(), self.periods, kind=_lib.KIND_RAYLEIGH | _lib.PHASE_ONLY,
-                                  nlay=nlay)
+                                  nlay=nlay, independent=self.independent)
         return c.to(torch.float64), st
 
     def misfit(self, params):

@@ -314,3 +314,41 @@ def test_unsorted_and_degenerate_periods_terminate(hip):
         assert c.shape == (64, len(per))
         c, u, st = hip.forward_batch(model, np.asarray(per, np.float32), 1)
         assert c.shape == (64, len(per))
+
+
+@pytest.mark.parametrize("case", ["synth_L5_R", "synth_L10_R", "synth_L10_L", "synth_L21_R", "synth_L64_R",
+                                  "synth_L64_L", "c1_single_L5_R", "two_layer_R"])
+def test_independent_mode_matches_reference_on_monotone_stacks(hip, ref_cases, case):
+    """SURFDISP_INDEPENDENT (one team per (stack, period), BASELINE north_star's work unit): on
+    monotone stacks with the dense 8-100 s period list it agrees with the reference to ~1e-6."""
+    d = ref_cases[case]
+    c, u, st = hip.forward_batch(d["model"], d["periods"], d["kind"], independent=True)
+    assert np.array_equal(c > 0, d["c"] > 0) and (st == 0).all()
+    assert relerr(c, d["c"]) < 1e-5 and relerr(u, d["u"]) < 2e-5
+
+
+@pytest.mark.parametrize("case,bound", [("dense18_L10_R", 5e-4), ("sparse_L10_R", 2e-2), ("water_L9_R", 2e-3)])
+def test_independent_mode_known_deviation_is_the_references_period_list_dependence(hip, ref_cases, case, bound):
+    """Where the reference's answer depends on the period LIST (mmax carry-over: only the layers
+    inside the previous period's effective half space are refreshed, calcul.f:112,133 - SURVEY.md
+    section 4 defect 2 measured 6e-5..2.4e-3) the independent mode solves each period on a fully
+    rebuilt stack and therefore differs by that amount; the faithful mode (default) does not.
+    This pins the size of the documented difference."""
+    d = ref_cases[case]
+    ci, ui, _ = hip.forward_batch(d["model"], d["periods"], d["kind"], independent=True)
+    cf, uf, _ = hip.forward_batch(d["model"], d["periods"], d["kind"])
+    assert relerr(cf, d["c"]) < TOL_C                       # faithful mode: parity
+    assert 1e-5 < relerr(ci, d["c"]) < bound                # independent mode: the carry-over effect
+
+
+def test_independent_mode_failure_cascade_and_water(hip, ref_cases):
+    """A failing period zeroes itself and all later ones (calcul.f:203-219), reduced over the
+    stack's teams; water stacks start the scan at 0.5 km/s in every period."""
+    d = ref_cases["lvz_halfspace_L4_R"]
+    c, u, st = hip.forward_batch(d["model"], d["periods"], 2, independent=True)
+    bad = np.argmax(c[0] == 0) if (c[0] == 0).any() else len(c[0])
+    assert not c[0, bad:].any() and not u[0, bad:].any()
+    assert st[0] == (0 if bad == len(c[0]) else (2 if bad == 0 else 1))
+    d = ref_cases["water_L9_L"]
+    c, u, st = hip.forward_batch(d["model"], d["periods"], 1, independent=True)
+    assert np.isfinite(c).all() and c.shape == d["c"].shape
