@@ -89,11 +89,18 @@ class TorchProposer:
         u = torch.rand((B, self.vmin.numel()), dtype=torch.float64, device=self.device, generator=self.gen)
         return self.vmin + (self.vmax - self.vmin) * u          # random.uniform(a, b) = a + (b-a)*random()
 
-    def move(self, v):
+    def move(self, v, rounds=12):
+        """Bounded Gaussian step.  The first ``rounds`` tries of every variable are drawn in one shot
+        ([B, rounds, N] candidates, first one inside the bounds wins); the rare leftovers go through
+        the reference's retry loop up to its 1000 tries, then the uniform fallback."""
         torch = self.torch
-        new = v + self.step * torch.randn(v.shape, dtype=torch.float64, device=self.device, generator=self.gen)
-        bad = ~((new < self.vmax) & (new > self.vmin))
-        tries = 1
+        draws = v[:, None, :] + self.step * torch.randn((v.shape[0], rounds, v.shape[1]), dtype=torch.float64,
+                                                        device=self.device, generator=self.gen)
+        ok = (draws < self.vmax) & (draws > self.vmin)
+        first = ok.to(torch.int8).argmax(dim=1, keepdim=True)
+        new = torch.gather(draws, 1, first).squeeze(1)
+        bad = ~ok.any(dim=1)
+        tries = rounds
         while tries < self.MAX_TRIES and bool(bad.any()):
             draw = v + self.step * torch.randn(v.shape, dtype=torch.float64, device=self.device, generator=self.gen)
             new = torch.where(bad, draw, new)

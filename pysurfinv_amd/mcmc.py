@@ -249,6 +249,63 @@ class MetropolisBatch:
         tr = self.run(C, chainL, init_first=False, _init_mask=first)
         return tr.reshape(n_points, chains_per_point, chainL, -1).cpu().numpy()
 
+    def run_graphed(self, n_chains, chainL, init_first=True, rounds=24):
+        """``run()`` with the whole Metropolis step - proposal, parameters -> stack, the forward
+        kernels, misfit, accept/reject, bookkeeping - captured ONCE in a HIP graph and replayed
+        ``chainL - 1`` times: at small chain counts the step is bound by the ~100 kernel launches of
+        the torch glue, not by the solver.  Requirements: device proposer (TorchProposer), no
+        ``isgood`` callback, a parameterisation with static structure (``Model1DBatch._static_sig``).
+        The bound-rejection loop of ``BrownianVar.move`` (<= 1000 tries, brownian.py:20-27) becomes a
+        fixed ``rounds`` redraws followed by the uniform fallback: a variable sitting exactly on a
+        bound survives 24 redraws with probability 6e-8, so the proposal distribution is unchanged
+        for all practical purposes.  Random numbers come from torch's default device generator
+        (graph-safe Philox)."""
+        torch = self.torch
+        if self.isgood is not None or not isinstance(self.proposer, TorchProposer) or self._forward is not None:
+            raise ValueError("run_graphed needs the device proposer, no isgood callback and the HIP forward path")
+        C, N = int(n_chains), self.spec.n
+        dev = self.device
+        pr = self.proposer
+        track = torch.zeros((C, chainL, 3 + N), dtype=torch.float64, device=dev)
+        p = self._start(C, init_first, None)
+        mis, chi, L = self.misfit(p)
+        track[:, 0, 0] = mis; track[:, 0, 1] = L; track[:, 0, 2] = 1.0; track[:, 0, 3:] = p
+        step = torch.ones(1, dtype=torch.int64, device=dev)          # row the next step writes
+        p = p.clone(); chi = chi.clone()
+
+        def one_step():
+            # all redraw rounds at once: [C, rounds, N] candidates, take the first one inside the bounds
+            draws = p[:, None, :] + pr.step * torch.randn((C, rounds, N), dtype=torch.float64, device=dev)
+            ok = (draws < pr.vmax) & (draws > pr.vmin)
+            first = ok.to(torch.int8).argmax(dim=1, keepdim=True)
+            chosen = torch.gather(draws, 1, first).squeeze(1)
+            uni = pr.vmin + (pr.vmax - pr.vmin) * torch.rand((C, N), dtype=torch.float64, device=dev)
+            new = torch.where(ok.any(dim=1), chosen, uni)
+            mis1, chi1, L1 = self.misfit(new)
+            better = chi1 < chi
+            u = torch.rand(C, dtype=torch.float64, device=dev)
+            acc = better | (~better & (u > 1.0 - torch.exp(-(chi1 - chi) / 2.0)))
+            row = torch.cat([mis1[:, None], L1[:, None], acc.to(torch.float64)[:, None], new], dim=1)
+            track.index_copy_(1, step, row[:, None, :])
+            p.copy_(torch.where(acc[:, None], new, p))
+            chi.copy_(torch.where(acc, chi1, chi))
+            step.add_(1)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                                # warm-up off the capture stream
+            one_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        if chainL > 2:                                              # rows 0 and 1 are written; capture
+            g = torch.cuda.CUDAGraph()                              # records one_step without running it
+            with torch.cuda.graph(g):
+                one_step()
+            for _ in range(chainL - 2):
+                g.replay()
+            self.n_forward += (chainL - 2) * C
+        return track
+
     # ------------------------------------------------------------------ output (point.py:82-85,120-123)
     @staticmethod
     def save_npz(outdir, pid, mc_track, setting, obs, chainL):

@@ -31,12 +31,12 @@ def oracle_forward(periods):
     return fwd
 
 
-def replay(device, forward):
+def replay(device, forward, independent=False):
     runN, chainL, seed = (int(x) for x in G["trace/meta"])
     mb = Model1DBatch(CONT, device=device)
     prop = brownian.PythonRandomProposer(mb.spec, device=device, seed=seed)
     mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], G["trace/c_obs"], G["trace/uncer"],
-                         device=device, proposer=prop, forward=forward)
+                         device=device, proposer=prop, forward=forward, independent=independent)
     chunks = [mc.run(1, chainL, init_first=(i == 0))[0] for i in range(runN // chainL)]
     return torch.cat(chunks, dim=0).cpu().numpy(), mc
 
@@ -106,6 +106,15 @@ def test_replay_reference_trace_gpu():
 
 
 @pytest.mark.gpu
+def test_replay_reference_trace_gpu_independent_mode():
+    """The smooth continental parameterisation with its dense 8-80 s period list is the regime where
+    the period-parallel root search equals the reference: the captured trace is reproduced step for
+    step in that mode too."""
+    track, mc = replay("cuda:0", None, independent=True)
+    check_trace(track)
+
+
+@pytest.mark.gpu
 def test_gpu_sampler_statistics_match_reference_trace():
     """512 chains x 80 steps on the GPU vs the reference's 3 chains: same acceptance behaviour
     (rate within a generous band) and the best misfit found is at least as good."""
@@ -141,3 +150,26 @@ def test_speculative_sampler_walks_a_consistent_chain():
     mc1 = MetropolisBatch(mb.spec, mb.to_model, per, G["trace/c_obs"], G["trace/uncer"], seed=5, **kw)
     tr1 = mc1.run(8, 31).numpy()
     assert abs(tr[:, 1:, 2].mean() - tr1[:, 1:, 2].mean()) < 0.2
+
+
+@pytest.mark.gpu
+def test_graphed_sampler_matches_plain_sampler_statistics():
+    """run_graphed(): the whole Metropolis step replayed from one HIP graph.  Same chain semantics as
+    run(): rows form valid chains, bounds hold, acceptance and best misfit agree with run()."""
+    mb = Model1DBatch(CONT, device="cuda:0")
+    kw = dict(device="cuda:0")
+    mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], G["trace/c_obs"], G["trace/uncer"], seed=1, **kw)
+    torch.cuda.manual_seed(11)
+    tg = mc.run_graphed(256, 60).cpu().numpy()
+    tp = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], G["trace/c_obs"], G["trace/uncer"], seed=2, **kw).run(256, 60).cpu().numpy()
+    assert tg.shape == tp.shape == (256, 60, 16)
+    assert np.isfinite(tg).all() and (tg[:, :, 3:] > mb.spec.vmin).all() and (tg[:, :, 3:] < mb.spec.vmax).all()
+    step = np.asarray(mb.spec.step)
+    for c in range(0, 256, 37):                                     # chain consistency
+        state = tg[c, 0, 3:]
+        for i in range(1, 60):
+            assert (np.abs(tg[c, i, 3:] - state) < 8 * step).all()
+            if tg[c, i, 2] == 1:
+                state = tg[c, i, 3:]
+    assert abs(tg[:, 1:, 2].mean() - tp[:, 1:, 2].mean()) < 0.05
+    assert abs(np.median(tg[:, -1, 0]) / np.median(tp[:, -1, 0]) - 1) < 0.25
