@@ -522,16 +522,20 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         } else if (st == ST_REFINE) {
             const float w = cb - p0c;
             cj = p0c + (float)(j + 1) * (w / (float)(G + 1));
-            if (G <= 4 && G > 1 && p0ok && w > 8.0f * CLUSTER_DC) {
+            if (G <= 4 && G > 1 && p0ok && w > 16.0f * CLUSTER_DC) {
                 // small teams: instead of G equidistant points, cluster them around the secant
                 // estimate (spacing CLUSTER_DC).  Delta(c) is smooth across a 0.01 bracket, so the
                 // root normally falls between two neighbours and the next acceptance test passes
                 // (one refine pass instead of two); if it does not, the sign pattern still shrinks
                 // the bracket and the next pass clusters around a better estimate.
                 float ts = -p0d * w / (db - p0d);
-                const float half = 0.5f * (float)(G - 1) * CLUSTER_DC;
+                // offsets in units of CLUSTER_DC: tight around the estimate, wider outside, so that a
+                // poorer estimate still lands between two points
+                const float off = (G == 4) ? ((j == 0) ? -4.0f : (j == 1) ? -1.0f : (j == 2) ? 1.0f : 4.0f)
+                                           : ((j == 0) ? -1.5f : 1.5f);
+                const float half = ((G == 4) ? 4.0f : 1.5f) * CLUSTER_DC;
                 ts = fminf(fmaxf(ts, half + CLUSTER_DC), w - half - CLUSTER_DC);
-                if (ts == ts) cj = p0c + (ts - half + (float)j * CLUSTER_DC);
+                if (ts == ts) cj = p0c + (ts + off * CLUSTER_DC);
             }
             mmj = mm_frozen;                                   // frozen as NEVILL sees it
         } else if (st == ST_ELLIP) {
