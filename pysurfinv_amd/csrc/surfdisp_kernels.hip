@@ -164,7 +164,7 @@ constexpr int NFW = 6;
 // ---- fast-but-tight fp32 helpers for the inner recursion --------------------------------------
 // The reference evaluates ~9 IEEE divisions, 2 sqrt and 2-4 libm calls per layer per trial
 // velocity.  Here: reciprocal = v_rcp_f32 + one Newton step (<= 1 ulp), sqrt = v_sqrt_f32 (1 ulp),
-// exp = v_exp_f32 on a split argument (~1 ulp), sincos = 3-constant Cody-Waite reduction + minimax
+// sinh/cosh = v_exp_f32 on a split argument (~1 ulp), sincos = 3-constant Cody-Waite reduction + minimax
 // polynomials (~1 ulp for |x| < 1e4).  Every one of these perturbs a matrix entry by ~1e-7
 // relative, i.e. like a 1e-7 relative change of a layer's thickness or velocity -- physically
 // nothing; measured end-to-end parity is unchanged.
@@ -174,17 +174,6 @@ __device__ __forceinline__ float rcp_nr(float x)
     return fmaf(r, fmaf(-x, r, 1.0f), r);
 }
 __device__ __forceinline__ float sqrt_hw(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ float exp_sp(float x)
-{
-    // e^x = 2^(x*log2e): split the product so the exponent argument keeps ~fp32 accuracy
-    const float L2E_HI = 1.44269502e+00f, L2E_LO = 1.92596299e-08f;
-    const float t = x * L2E_HI;
-    const float tl = fmaf(x, L2E_HI, -t) + x * L2E_LO;      // low part of x*log2(e)
-    const float ti = __builtin_rintf(t);
-    const float tf = (t - ti) + tl;                          // |tf| <= 0.5 (+eps)
-    const float p = __builtin_amdgcn_exp2f(tf);
-    return __builtin_amdgcn_ldexpf(p, (int)ti);
-}
 // sinh(x), cosh(x) from one split product: 0.5*e^x = 2^(t-1)*(1 + tl*ln2), 0.5*e^-x likewise
 __device__ __forceinline__ void sinhcosh_sp(float x, float *sh, float *ch)
 {
@@ -745,40 +734,6 @@ SD_HD __forceinline__ Drop drop_group(const float *__restrict__ mdl, size_t fs, 
 
 // ---- Rayleigh, surfa.f:714-1192 ---------------------------------------------------------------
 struct RCoef { float a12, a13, a21, a24, a31, a34, a42, a43, ddz; };
-
-SD_HD __forceinline__ void rk4_step(const RCoef &q, double &ur, double &uz, double &tz, double &tr)
-{
-    // classical RK4 with the reference's fp32 weights (surfa.f:764-771, 955-968).
-    // Written with EXPLICIT fma() and contraction off: group_rayleigh() integrates the same
-    // solutions twice (surface values first, energy integrals second) and the two sweeps must be
-    // bit-identical -- the combination xnorm*y+z cancels ~1e6, so a compiler that fuses one
-    // instantiation differently from the other would destroy the integrals.
-#pragma clang fp contract(off)
-    const double w_half = (double)(0.5f * q.ddz), w_one = (double)(1.0f * q.ddz);
-    const double t6 = (double)((1.0f / 6.0f) * q.ddz), t3 = (double)((1.0f / 3.0f) * q.ddz);
-    const double a12 = q.a12, a13 = q.a13, a21 = q.a21, a24 = q.a24, a31 = q.a31, a34 = q.a34,
-                 a42 = q.a42, a43 = q.a43;
-    double d1, d2, d3, d4, e1, e2, e3, e4, s1, s2, s3, s4;
-    // stage 1 (wwt = 0)
-    d1 = fma(a31, uz, a34 * tr); d2 = fma(a12, tz, a13 * ur);
-    d3 = fma(a21, uz, a24 * tr); d4 = fma(a42, tz, a43 * ur);
-    e1 = fma(t6, d1, ur); e2 = fma(t6, d2, uz); e3 = fma(t6, d3, tz); e4 = fma(t6, d4, tr);
-    // stage 2
-    s1 = fma(w_half, d1, ur); s2 = fma(w_half, d2, uz); s3 = fma(w_half, d3, tz); s4 = fma(w_half, d4, tr);
-    d1 = fma(a31, s2, a34 * s4); d2 = fma(a12, s3, a13 * s1);
-    d3 = fma(a21, s2, a24 * s4); d4 = fma(a42, s3, a43 * s1);
-    e1 = fma(t3, d1, e1); e2 = fma(t3, d2, e2); e3 = fma(t3, d3, e3); e4 = fma(t3, d4, e4);
-    // stage 3
-    s1 = fma(w_half, d1, ur); s2 = fma(w_half, d2, uz); s3 = fma(w_half, d3, tz); s4 = fma(w_half, d4, tr);
-    d1 = fma(a31, s2, a34 * s4); d2 = fma(a12, s3, a13 * s1);
-    d3 = fma(a21, s2, a24 * s4); d4 = fma(a42, s3, a43 * s1);
-    e1 = fma(t3, d1, e1); e2 = fma(t3, d2, e2); e3 = fma(t3, d3, e3); e4 = fma(t3, d4, e4);
-    // stage 4
-    s1 = fma(w_one, d1, ur); s2 = fma(w_one, d2, uz); s3 = fma(w_one, d3, tz); s4 = fma(w_one, d4, tr);
-    d1 = fma(a31, s2, a34 * s4); d2 = fma(a12, s3, a13 * s1);
-    d3 = fma(a21, s2, a24 * s4); d4 = fma(a42, s3, a43 * s1);
-    ur = fma(t6, d1, e1); uz = fma(t6, d2, e2); tz = fma(t6, d3, e3); tr = fma(t6, d4, e4);
-}
 
 struct RInt {                       // energy integrals, fp64 accumulators (reference: fp32 sumi*)
     double i0, i1, i2;
