@@ -105,6 +105,18 @@ int surfdisp_forward_batch_device_timed(void *stream, int B, int Lmax, const int
                                         float *c, float *u, int *status,
                                         void *workspace, size_t workspace_bytes, float *kernel_ms);
 
+/* ---- (5) non-blocking measurement: the caller creates events (surfdisp_events_create), passes
+ *          four per call; they are recorded on `stream` before prep, after prep, after the root
+ *          search and after group+finish.  Read with surfdisp_events_elapsed_ms once the caller has
+ *          synchronised.  bench.py records them inside its timed region. */
+int surfdisp_forward_batch_device_events(void *stream, int B, int Lmax, const int *nlay,
+                                         const float *model, int P, const float *per, int kind,
+                                         float *c, float *u, int *status,
+                                         void *workspace, size_t workspace_bytes, void *const *events4);
+int surfdisp_events_create(int n, void **events);
+int surfdisp_events_destroy(int n, void **events);
+int surfdisp_events_elapsed_ms(void *start, void *stop, float *ms);
+
 /* ---- tuning / introspection ------------------------------------------------------------- */
 /* lanes of one wavefront that cooperate on one stack's root search (1,2,4,...,64); 0 = choose
  * from (B, Lmax).  Also settable through the environment variable SURFDISP_TEAM. */

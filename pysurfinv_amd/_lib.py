@@ -21,7 +21,9 @@ NPER_MAX, NLAY_MAX = 200, 200
 # every symbol include/surfdisp.h declares
 EXPORTS = (
     "fast_surf_", "surfdisp_forward_batch", "surfdisp_workspace_bytes",
-    "surfdisp_forward_batch_device", "surfdisp_forward_batch_device_timed", "surfdisp_set_team", "surfdisp_get_team",
+    "surfdisp_forward_batch_device", "surfdisp_forward_batch_device_timed",
+    "surfdisp_forward_batch_device_events", "surfdisp_events_create", "surfdisp_events_destroy",
+    "surfdisp_events_elapsed_ms", "surfdisp_set_team", "surfdisp_get_team",
     "surfdisp_device_count", "surfdisp_abi_version", "surfdisp_last_error",
     "surfdisp_kernel_name",
 )
@@ -70,6 +72,16 @@ def lib() -> ctypes.CDLL:
     L.surfdisp_forward_batch_device_timed.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp,
                                                       ctypes.c_int, vp, ctypes.c_int, vp, vp, vp,
                                                       vp, ctypes.c_size_t, fp]
+    L.surfdisp_forward_batch_device_events.restype = ctypes.c_int
+    L.surfdisp_forward_batch_device_events.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp,
+                                                       ctypes.c_int, vp, ctypes.c_int, vp, vp, vp,
+                                                       vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.surfdisp_events_create.restype = ctypes.c_int
+    L.surfdisp_events_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.surfdisp_events_destroy.restype = ctypes.c_int
+    L.surfdisp_events_destroy.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.surfdisp_events_elapsed_ms.restype = ctypes.c_int
+    L.surfdisp_events_elapsed_ms.argtypes = [vp, vp, fp]
     L.surfdisp_set_team.restype = ctypes.c_int
     L.surfdisp_set_team.argtypes = [ctypes.c_int]
     L.surfdisp_get_team.restype = ctypes.c_int

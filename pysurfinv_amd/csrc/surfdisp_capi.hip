@@ -184,6 +184,47 @@ int surfdisp_forward_batch_device(void *stream, int B, int Lmax, const int *nlay
                                workspace, workspace_bytes, nullptr);
 }
 
+// Measurement variant that does NOT synchronise: the caller owns four events per call
+// (surfdisp_events_create) which are recorded on the launch stream before prep, between the
+// kernels and after finish; durations are read later with surfdisp_events_elapsed_ms, after the
+// caller's own synchronisation.  This is what bench.py uses inside its timed region.
+int surfdisp_forward_batch_device_events(void *stream, int B, int Lmax, const int *nlay,
+                                         const float *model, int P, const float *per, int kind,
+                                         float *c, float *u, int *status,
+                                         void *workspace, size_t workspace_bytes, void *const *events4)
+{
+    if (!events4) { set_err("events4 is NULL"); return SURFDISP_ERR_INVALID; }
+    hipEvent_t ev[4];
+    for (int i = 0; i < 4; ++i) ev[i] = static_cast<hipEvent_t>(events4[i]);
+    return forward_device_impl(stream, B, Lmax, nlay, model, P, per, kind, c, u, status,
+                               workspace, workspace_bytes, ev);
+}
+
+int surfdisp_events_create(int n, void **events)
+{
+    if (n < 0 || !events) { set_err("bad events array"); return SURFDISP_ERR_INVALID; }
+    for (int i = 0; i < n; ++i) {
+        hipEvent_t e;
+        SD_HIP(hipEventCreate(&e));
+        events[i] = e;
+    }
+    return SURFDISP_SUCCESS;
+}
+
+int surfdisp_events_destroy(int n, void **events)
+{
+    if (!events) return SURFDISP_ERR_INVALID;
+    for (int i = 0; i < n; ++i) if (events[i]) (void)hipEventDestroy(static_cast<hipEvent_t>(events[i]));
+    return SURFDISP_SUCCESS;
+}
+
+int surfdisp_events_elapsed_ms(void *start, void *stop, float *ms)
+{
+    if (!start || !stop || !ms) { set_err("NULL event"); return SURFDISP_ERR_INVALID; }
+    SD_HIP(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+    return SURFDISP_SUCCESS;
+}
+
 // Measurement variant: same launches, bracketed by HIP events recorded ON THE LAUNCH STREAM;
 // waits for completion and returns the three kernel durations in milliseconds
 // (kernel_ms[0..2] = prep, phase, group).  Not capturable in a graph (it synchronises).

@@ -96,7 +96,9 @@ class BatchPlan:
         measured with HIP events on the launch stream (surfdisp_forward_batch_device_timed)."""
         return self.run(model, periods, kind=kind, nlay=nlay, _timed=True, independent=independent)
 
-    def run(self, model, periods, kind=2, nlay=None, _timed=False, independent=False):
+    def run(self, model, periods, kind=2, nlay=None, _timed=False, independent=False, events=None):
+        """Launch the kernels on torch's current stream (no allocation, no sync).  ``events``: an
+        ``EventRing`` slot (4 HIP events recorded on the launch stream around the kernels)."""
         torch = self.torch
         if independent:
             kind = int(kind) | _lib.INDEPENDENT
@@ -120,9 +122,43 @@ class BatchPlan:
                 rc = _lib.lib().surfdisp_forward_batch_device_timed(*args, ms)
                 _lib.check(rc)
                 return self.c, self.u, self.status, tuple(float(x) for x in ms)
-            rc = _lib.lib().surfdisp_forward_batch_device(*args)
+            if events is not None:
+                rc = _lib.lib().surfdisp_forward_batch_device_events(*args, events)
+            else:
+                rc = _lib.lib().surfdisp_forward_batch_device(*args)
         _lib.check(rc)
         return self.c, self.u, self.status
+
+
+class EventRing:
+    """n x 4 HIP events owned by the caller, recorded by ``BatchPlan.run(..., events=ring.slot(i))``
+    on the launch stream; ``kernel_ms()`` (after the caller synchronised) returns the
+    [n, 3] prep / root-search / group+finish durations in milliseconds."""
+
+    def __init__(self, n):
+        self.n = int(n)
+        self._ev = (ctypes.c_void_p * (4 * self.n))()
+        _lib.check(_lib.lib().surfdisp_events_create(4 * self.n, self._ev))
+
+    def slot(self, i):
+        return ctypes.cast(ctypes.byref(self._ev, 4 * (i % self.n) * ctypes.sizeof(ctypes.c_void_p)),
+                           ctypes.POINTER(ctypes.c_void_p))
+
+    def kernel_ms(self, used=None):
+        out = np.zeros((self.n if used is None else used, 3))
+        ms = ctypes.c_float()
+        for i in range(out.shape[0]):
+            for k in range(3):
+                _lib.check(_lib.lib().surfdisp_events_elapsed_ms(self._ev[4 * i + k], self._ev[4 * i + k + 1],
+                                                                 ctypes.byref(ms)))
+                out[i, k] = ms.value
+        return out
+
+    def __del__(self):
+        try:
+            _lib.lib().surfdisp_events_destroy(4 * self.n, self._ev)
+        except Exception:
+            pass
 
 
 def forward_batch_torch(model, periods, kind=2, nlay=None):
