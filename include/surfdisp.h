@@ -117,6 +117,14 @@ int surfdisp_events_create(int n, void **events);
 int surfdisp_events_destroy(int n, void **events);
 int surfdisp_events_elapsed_ms(void *start, void *stop, float *ms);
 
+/* ---- (6) parameters -> layer stacks on the device (the row next to the hot path, SURVEY.md 8f-2:
+ *          Model1D.seisPropLayers, models.py:72-102 + layers.py:139-284) for models with a static
+ *          layer structure.  params [C][N] fp64, model [C][5][L] fp32 (rows vp, vs, rho, h, 1/Qs);
+ *          idesc / fdesc: descriptor built by pysurfinv_amd.layers_batch (layout in
+ *          csrc/surfdisp_layers.hip).  All device pointers; stream-ordered; graph-capturable. */
+int surfdisp_params_to_model_device(void *stream, int C, int N, int L, const double *params,
+                                    const int *idesc, const double *fdesc, float *model);
+
 /* ---- tuning / introspection ------------------------------------------------------------- */
 /* lanes of one wavefront that cooperate on one stack's root search (1,2,4,...,64); 0 = choose
  * from (B, Lmax).  Also settable through the environment variable SURFDISP_TEAM. */

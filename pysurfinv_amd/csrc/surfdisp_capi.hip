@@ -184,6 +184,20 @@ int surfdisp_forward_batch_device(void *stream, int B, int Lmax, const int *nlay
                                workspace, workspace_bytes, nullptr);
 }
 
+// Parameters -> layer stacks on the device for a static-structure model; the
+// descriptor layout is documented in surfdisp_layers.hip and built by pysurfinv_amd.layers_batch.
+int surfdisp_params_to_model_device(void *stream, int C, int N, int L, const double *params,
+                                    const int *idesc, const double *fdesc, float *model)
+{
+    if (C < 1 || N < 0 || L < 2 || L > SURFDISP_NLAY_MAX || !params || !idesc || !fdesc || !model) {
+        set_err("surfdisp_params_to_model_device: bad argument");
+        return SURFDISP_ERR_INVALID;
+    }
+    sd::LayersArgs a{C, N, params, idesc, fdesc, model};
+    SD_HIP(sd::launch_layers(static_cast<hipStream_t>(stream), a, L));
+    return SURFDISP_SUCCESS;
+}
+
 // Measurement variant that does NOT synchronise: the caller owns four events per call
 // (surfdisp_events_create) which are recorded on the launch stream before prep, between the
 // kernels and after finish; durations are read later with surfdisp_events_elapsed_ms, after the

@@ -51,6 +51,15 @@ struct FinishArgs {
     int *status;
 };
 
+struct LayersArgs {
+    int C, N;
+    const double *params;  // [C][N]
+    const int *idesc;      // see surfdisp_layers.hip
+    const double *fdesc;
+    float *model;          // [C][5][L]
+};
+hipError_t launch_layers(hipStream_t s, const LayersArgs &a, int L);
+
 size_t phase_lds_bytes(int Lmax, int G);
 hipError_t launch_finish(hipStream_t s, const FinishArgs &a);
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a);

@@ -325,9 +325,90 @@ class Model1DBatch:
                 if static else int(nlay.max().item()))
         return tuple(o[:, :Lmax] for o in out), nlay
 
+    # ------------------------------------------------------------------ native (HIP) path
+    KIND_CODE = {"sed": 0, "crust": 1, "mantle": 2, "water": 3, "osed": 4, "ocrust": 5}
+
+    def native_descriptor(self):
+        """(idesc int32, fdesc float64, L) for csrc/surfdisp_layers.hip, or None when the layer
+        structure is not static.  Cached on the model's device."""
+        if self._static_sig is None or len(self.layers) > 10:
+            return None
+        if getattr(self, "_native_desc", None) is not None:
+            return self._native_desc
+        torch = self.torch
+        nin = len(self.layers)
+        ref = bool(self.info.get("refLayer", False))
+        lay_i, coef_i, lay_f, grid_f, tops = [], [], [], [], []
+        g = 0
+        for lay, N in zip(self.layers, self._static_sig):
+            hs = lay["H"]
+            slots = lay["Vs"]
+            if len(slots) > 8:
+                return None
+            begin, end = g, g + N + 1
+            lay_i += [self.KIND_CODE[lay["kind"]], hs.idx if hs.idx is not None else -1,
+                      1 if lay.get("Hkey") == "BottomDepth" else 0, len(slots), begin, end, 0, 0]
+            coef_i += [(sl.idx if sl.idx is not None else -1) for sl in slots] + [-1] * (8 - len(slots))
+            lay_f += [float(hs.const) if hs.const is not None else 0.0]
+            lay_f += [(float(sl.const) if sl.const is not None else 0.0) for sl in slots] + [0.0] * (8 - len(slots))
+            kind, nb = lay["kind"], len(slots)
+            bas = None
+            if kind in ("crust", "mantle"):
+                bas = bspline_basis(N + 1, nb, lay.get("deg"))          # [nb, N+1]
+            for q in range(N + 1):
+                t = float(np.linspace(0.0, 1.0, N + 1)[q])
+                if kind == "water":
+                    row = []
+                elif kind in ("crust", "mantle"):
+                    row = [float(bas[k, q]) for k in range(nb)]
+                elif nb == 2 and kind in ("sed", "ocrust"):
+                    row = [1.0 - t, t]
+                else:
+                    row = [1.0]
+                grid_f += [t] + row + [0.0] * (8 - len(row))
+            tops += list(range(begin, end - 1))
+            g = end
+        ngrid = g
+        if ref:
+            tops += list(range(ngrid, ngrid + 20))
+        L = len(tops)
+        idesc = [nin, ngrid, L, 1 if ref else 0] + lay_i + coef_i + tops
+        topo = float(self.info.get("topo", 0.0))
+        fdesc = [-max(topo, 0.0)] + lay_f + grid_f
+        self._native_desc = (torch.tensor(idesc, dtype=torch.int32, device=self.device),
+                             torch.tensor(fdesc, dtype=torch.float64, device=self.device), L)
+        return self._native_desc
+
+    def to_model_native(self, params):
+        """``to_model`` through the HIP kernel surfdisp_layers_kernel (one launch, graph-capturable)."""
+        import ctypes
+        from . import _lib
+        torch = self.torch
+        desc = self.native_descriptor()
+        if desc is None or params.device.type != "cuda":
+            raise _lib.SurfdispError("native parameters->stack needs a static layer structure and a HIP device")
+        idesc, fdesc, L = desc
+        p = params.to(torch.float64).contiguous()
+        C, N = p.shape
+        model = torch.empty((C, 5, L), dtype=torch.float32, device=p.device)
+        stream = torch.cuda.current_stream(p.device).cuda_stream
+        with torch.cuda.device(p.device):
+            rc = _lib.lib().surfdisp_params_to_model_device(
+                ctypes.c_void_p(stream), C, N, L, ctypes.c_void_p(p.data_ptr()),
+                ctypes.c_void_p(idesc.data_ptr()), ctypes.c_void_p(fdesc.data_ptr()),
+                ctypes.c_void_p(model.data_ptr()))
+        _lib.check(rc)
+        return model, None
+
     def to_model(self, params):
         """model float32 [B, 5, Lmax] rows (vp, vs, rho, h, 1/Qs) + nlay - what ``_calForward``
-        hands to ``fast_surf`` (models.py:20-27)."""
+        hands to ``fast_surf`` (models.py:20-27).  On a HIP device with a static layer structure this
+        is one kernel launch (``to_model_native``); otherwise the torch implementation below."""
+        if params.device.type == "cuda" and self.native_descriptor() is not None:
+            return self.to_model_native(params)
+        return self.to_model_torch(params)
+
+    def to_model_torch(self, params):
         torch = self.torch
         (h, vs, vp, rho, qs, qp), nlay = self.seis_prop_layers(params)
         qsinv = torch.where(qs > 0, 1.0 / torch.where(qs > 0, qs, torch.ones_like(qs)), torch.zeros_like(qs))

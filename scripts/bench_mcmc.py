@@ -39,7 +39,7 @@ for name, chains, steps, depth in (("configs[2] single point: 100 chains (100 00
     t1 = time.perf_counter()
     for _ in range(5): mc.forward_c(p)
     torch.cuda.synchronize(); t_fwd = (time.perf_counter() - t1) / 5 - t_model
-    print(json.dumps({"independent": IND, "config": name, "chains": chains, "steps_timed": steps, "spec_depth": depth, "layers": int(nl.max()),
+    print(json.dumps({"independent": IND, "config": name, "chains": chains, "steps_timed": steps, "spec_depth": depth, "layers": int(m.shape[2]),
                       "metropolis_steps_per_s": chains * steps / dt, "ms_per_lockstep": dt / steps * 1e3,
                       "ms_params_to_stack": t_model * 1e3, "ms_forward_phase_only": t_fwd * 1e3,
                       "accept_rate": float(tr[:, 1:, 2].mean())}), flush=True)

@@ -63,3 +63,28 @@ def test_torch_proposer_respects_bounds_and_step():
     r = pr.reset(20000)
     assert bool(((r >= lo) & (r <= hi)).all())
     assert abs(r[:, 3].mean().item() - 35.0) < 0.3                 # uniform on (25, 45)
+
+
+@pytest.mark.gpu
+def test_native_params_to_model_kernel_matches_torch_path_and_reference():
+    """csrc/surfdisp_layers.hip (one launch) against the torch implementation and, through it, the
+    reference's seisPropLayers outputs."""
+    m = Model1DBatch(CONT, device="cuda:0")
+    assert m.native_descriptor() is not None
+    params = torch.from_numpy(G["cont/params"]).cuda()
+    mt, nl = m.to_model_torch(params)
+    mn, nn = m.to_model_native(params)
+    torch.cuda.synchronize()
+    assert nn is None and mn.shape == mt.shape == (40, 5, 96)
+    assert float((mn - mt).abs().max()) < 2e-6                       # fp32 rounding of fp64 values
+    ref = G["cont/layers"]
+    assert np.allclose(mn[:, 1].cpu().numpy(), ref[:, 1], atol=1e-6)  # vs
+    assert np.allclose(mn[:, 3].cpu().numpy(), ref[:, 0], atol=1e-5)  # h
+    assert np.allclose(mn[:, 0].cpu().numpy(), ref[:, 2], atol=1e-6)  # vp
+    assert np.allclose(mn[:, 2].cpu().numpy(), ref[:, 3], atol=1e-6)  # rho
+    assert np.allclose(1.0 / mn[:, 4].cpu().numpy(), ref[:, 4], rtol=1e-6)
+    # the oceanic setting's structure is not static inside its prior box: torch path is used
+    mo = Model1DBatch(OCEAN, device="cuda:0")
+    assert mo.native_descriptor() is None
+    model, nlay = mo.to_model(torch.from_numpy(G["ocean/params"]).cuda())
+    assert np.array_equal(nlay.cpu().numpy(), G["ocean/nlay"])
