@@ -24,6 +24,7 @@
 // write of c/U; everything else is VALU + transcendental work.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "surfdisp_internal.h"
 
 #define SD_HD __host__ __device__
@@ -807,7 +808,13 @@ SD_HD __forceinline__ void prop_apply(const RProp &P, double v[4])
 // accumulate the Boole energy integrals of the combined solution (xnorm*y + z)/bb
 // (surfa.f:1087-1129).  The two sweeps agree to fp64 rounding (~1e-15 relative), far inside what the
 // ~1e6 cancellation of the combination needs.
-template <bool INTEG>
+// MODE 0: surface values only, one application of P^4 per sublayer (fast path);
+// MODE 1: surface values only, four applications of P per sublayer - bit-identical to what MODE 2
+//         computes, which the robust path needs (see group_rayleigh);
+// MODE 2: energy integrals.  two_vec = false: z[] is the combined solution itself (fast path);
+//         two_vec = true: y[] and z[] are stepped separately and combined at every knot with the
+//         fitted xnorm / bb, exactly like the reference's stored knots (surfa.f:1092-1095).
+template <int MODE>
 SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t fs, int B, int b,
                                                int n, float lnT, int ndiv, bool water, float div,
                                                const Drop dr, float wvno, float wvnosq, float omegsq,
@@ -837,7 +844,7 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
         q.a42 = -q.a13;
         q.a43 = q.a21 + 4.0f * wvnosq * xmu * (xlamb + xmu) * q.a12;
         const RProp P = make_prop(q);
-        if (!INTEG) {
+        if (MODE == 0) {
             const RProp P4 = prop_sq(prop_sq(P));
             for (int s = 0; s < nreg; ++s) {
                 if (do_y) prop_apply(P4, y);
@@ -845,13 +852,32 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
             }
             continue;
         }
+        if (MODE == 1) {
+            for (int s = 0; s < nreg; ++s) {
+#pragma unroll
+                for (int kk = 3; kk >= 0; --kk) {
+                    if (do_y) prop_apply(P, y);
+                    prop_apply(P, z);
+                }
+            }
+            continue;
+        }
+        const bool two_vec = do_y;
         const float dz = dsub / 4.0f;
         const float l2m = xlamb + 2.0f * xmu;
         const float ixmu = q.a34, il2m = q.a12;       // 1/mu, 1/(lambda+2mu): already formed above
         float f_mr[5], f_mz[5], f_rz[5], f_zr[5];
+        const double ibb = 1.0 / bbn;
         auto knot = [&](int kk) {
-            // in this sweep z[] is the combined, normalised solution (xnorm*y + z)/bb itself
-            const float aur = (float)z[0], auz = (float)z[1], atz = (float)z[2], atr = (float)z[3];
+            // fast path: z[] is the combined, normalised solution (xnorm*y + z)/bb itself;
+            // robust path: combine the separately integrated solutions at the knot
+            float aur, auz, atz, atr;
+            if (two_vec) {
+                aur = (float)((xnorm * y[0] + z[0]) * ibb); auz = (float)((xnorm * y[1] + z[1]) * ibb);
+                atz = (float)((xnorm * y[2] + z[2]) * ibb); atr = (float)((xnorm * y[3] + z[3]) * ibb);
+            } else {
+                aur = (float)z[0]; auz = (float)z[1]; atz = (float)z[2]; atr = (float)z[3];
+            }
             const float durdz = atr * ixmu - wvno * auz;
             const float duzdz = (atz + wvno * xlamb * aur) * il2m;
             f_mr[kk] = aur * aur; f_mz[kk] = auz * auz;
@@ -863,6 +889,7 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
             else { f_mr[4] = f_mr[0]; f_mz[4] = f_mz[0]; f_rz[4] = f_rz[0]; f_zr[4] = f_zr[0]; }
 #pragma unroll
             for (int kk = 3; kk >= 0; --kk) {
+                if (two_vec) prop_apply(P, y);
                 prop_apply(P, z);
                 knot(kk);
             }
@@ -942,53 +969,71 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
     const double y0[4] = {1.0, 0.0, (double)(-h * brkt / det), (double)(-h * ra / det)};   // ur,uz,tz,tr
     double z0[4] = {0.0, 1.0, (double)(-h * rb / det), (double)(-h * brkt / det)};
     double y[4], z[4];
-    // pass 1: surface values of both solutions
-    for (int i = 0; i < 4; ++i) { y[i] = y0[i]; z[i] = z0[i]; }
-    rayleigh_sweep<false>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
-                          y, z, true, 0.0, 1.0, acc);
-    const double yt[4] = {y[0], y[1], y[2], y[3]};
-    if (dbg) { for (int i = 0; i < 4; ++i) { dbg[i] = y[i]; dbg[4 + i] = z[i]; } dbg[12] = dr.hs_layer; dbg[13] = dr.nreg_hs; dbg[14] = ndiv; }
-    double xnorm, bbn;
-    {   // surfa.f:1056-1069
+    double xnorm = 0.0, bbn = 1.0;
+    // Surface fit (surfa.f:1056-1069) + one refinement (restart solution 2 from the combined start
+    // vector, surfa.f:990-998).  STEP = 0: P^4 per sublayer; STEP = 1: step by step.
+    auto fit = [&](auto step_tag) -> double {
+        constexpr int STEP = decltype(step_tag)::value;
+        for (int i = 0; i < 4; ++i) { y[i] = y0[i]; z[i] = z0[i]; }
+        rayleigh_sweep<STEP>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
+                             y, z, true, 0.0, 1.0, acc);
+        const double yt0 = y[0], yt1 = y[1];
         double aa = z[0] - ratio * z[1];
-        double bb = ratio * yt[1] - yt[0];
+        double bb = ratio * yt1 - yt0;
         if (fabs(bb) < 1.e-10) bb = copysign(1.e-10, bb);
         xnorm = aa / bb;
-        bb = xnorm * yt[1] + z[1];
+        bb = xnorm * yt1 + z[1];
         if (fabs(bb) < 1.e-10) bb = copysign(1.e-10, bb);
         bbn = bb;
-        const float ampur = (float)((xnorm * yt[0] + z[0]) / bb);
+        const float ampur = (float)((xnorm * yt0 + z[0]) / bb);
         const float xtest = fabsf(ampur / ratio - 1.0f);
         if (xtest >= 0.00001f) {
-            // one refinement: restart solution 2 from the combined vector (surfa.f:990-998)
             for (int i = 0; i < 4; ++i) { z0[i] = z0[i] + xnorm * y0[i]; z[i] = z0[i]; }
-            rayleigh_sweep<false>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
-                                  y, z, false, 0.0, 1.0, acc);
+            rayleigh_sweep<STEP>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
+                                 y, z, false, 0.0, 1.0, acc);
             aa = z[0] - ratio * z[1];
-            bb = ratio * yt[1] - yt[0];
+            bb = ratio * yt1 - yt0;
             if (fabs(bb) < 1.e-10) bb = copysign(1.e-10, bb);
             xnorm = aa / bb;
-            bb = xnorm * yt[1] + z[1];
+            bb = xnorm * yt1 + z[1];
             if (fabs(bb) < 1.e-10) bb = copysign(1.e-10, bb);
             bbn = bb;
         }
-    }
-    if (dbg) { dbg[8] = xnorm; dbg[9] = bbn; }
-    // sweep 2: integrate the COMBINED solution w = (xnorm*y + z)/bb itself (one 4-vector instead of
-    // two) and accumulate the energy integrals.  The RK4 map is linear, so this equals combining
-    // separately integrated y and z (what the reference does with its stored knots) up to fp64
-    // rounding times the ~1e6 cancellation, i.e. ~1e-10 relative -- invisible after the fp32
-    // rounding of the knot values; it is also what the reference's own refinement pass integrates
-    // (surfa.f:990-998).
-    for (int i = 0; i < 4; ++i) { z[i] = (xnorm * y0[i] + z0[i]) / bbn; y[i] = 0.0; }
+        // growth of the fastest solution relative to the normalisation: rounding noise injected at
+        // the bottom of a direct integration of the combined solution reaches eps * this at the top
+        return fmax(fmax(fabs(yt0), fabs(yt1)), fmax(fabs(z[0]), fabs(z[1]))) / fabs(bbn);
+    };
+    const double z0_orig[4] = {z0[0], z0[1], z0[2], z0[3]};
+    const double cancel = fit(std::integral_constant<int, 0>{});
+    if (dbg) { for (int i = 0; i < 4; ++i) { dbg[i] = y[i]; dbg[4 + i] = z[i]; } dbg[12] = dr.hs_layer; dbg[13] = dr.nreg_hs; dbg[14] = ndiv; dbg[8] = xnorm; dbg[9] = bbn; }
     // half-space analytic terms use the combined vector at the top of the half space
-    float aur = (float)z[0];
-    float auz = (float)z[1];
+    float aur, auz;
     const bool any_solid = (dr.hs_layer > (wet ? 1 : 0)) || (dr.nreg_hs > 0);
-    if (wet && !any_solid) { aur = ratio; auz = 1.0f; }              // label 77777, surfa.f:1140-1144
     (void)tzz;
-    rayleigh_sweep<true>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
-                         y, z, false, xnorm, bbn, acc);
+    if (cancel <= 1.0e7) {
+        // Fast path.  Integrate the COMBINED solution w = (xnorm*y + z)/bb itself (one 4-vector): the
+        // RK4 map is linear, so this equals combining separately integrated y and z up to the
+        // rounding noise the fastest-growing solution picks up on the way (<= 1e7 * 1e-16).
+        for (int i = 0; i < 4; ++i) { z[i] = (xnorm * y0[i] + z0[i]) / bbn; y[i] = 0.0; }
+        aur = (float)z[0]; auz = (float)z[1];
+        rayleigh_sweep<2>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
+                          y, z, false, xnorm, bbn, acc);
+    } else {
+        // Robust path (thick structure / short period: the solutions grow by up to ~1e27 and the
+        // rounding noise excited on the way up is far larger than the answer).  The reference stays
+        // accurate here because it combines the SAME stored knot values its fit was made with, so
+        // the excited noise cancels exactly.  Do the same without storing: redo the fit step by
+        // step, then step y and z again with bit-identical arithmetic (make_prop / prop_apply are
+        // built with contraction off and explicit fma) and combine at every knot.
+        for (int i = 0; i < 4; ++i) z0[i] = z0_orig[i];
+        (void)fit(std::integral_constant<int, 1>{});
+        for (int i = 0; i < 4; ++i) { y[i] = y0[i]; z[i] = z0[i]; }
+        aur = (float)((xnorm * y0[0] + z0[0]) / bbn);
+        auz = (float)((xnorm * y0[1] + z0[1]) / bbn);
+        rayleigh_sweep<2>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
+                          y, z, true, xnorm, bbn, acc);
+    }
+    if (wet && !any_solid) { aur = ratio; auz = 1.0f; }              // label 77777, surfa.f:1140-1144
     {   // label 7002, surfa.f:1145-1186
         const float xmu = hsv.rho * hsv.b * hsv.b;
         const float xlamb = hsv.rho * (hsv.a * hsv.a - 2.0f * hsv.b * hsv.b);

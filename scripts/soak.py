@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Randomised differential soak: HIP path vs CPU oracle over random stacks / period lists / team
+sizes.  Reports the worst disagreements; exits non-zero on a hang-free but wrong result."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pysurfinv_amd import _lib, forward, synth
+from oracle import cport
+
+rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "0")))
+T_END = time.time() + float(os.environ.get("SOAK_SECONDS", "120"))
+worst = dict(c=0.0, u=0.0)
+nstack = ncase = npat = 0
+bad_cases = []
+while time.time() < T_END:
+    L = int(rng.integers(2, 48)); B = int(rng.integers(64, 2048)); kind = int(rng.integers(1, 3))
+    noise = float(rng.choice([0.02, 0.05, 0.1, 0.2])); mono = bool(rng.random() < 0.6)
+    model = synth.synth_models(B, L, seed=int(rng.integers(1 << 30)), noise=noise, monotone=mono,
+                               total_thickness=float(rng.choice([60., 120., 200., 400.])))
+    if rng.random() < 0.2 and L >= 4:                       # water + sediment on top
+        model[:, 1, 0] = 0.0; model[:, 0, 0] = 1.475; model[:, 2, 0] = 1.027; model[:, 4, 0] = 1e-4
+        model[:, 3, 0] = rng.uniform(0.3, 4.0, B)
+        model[:, 1, 1] = rng.uniform(0.6, 1.8, B); model[:, 0, 1] = 1.23 * model[:, 1, 1] + 1.28
+        model[:, 3, 1] = rng.uniform(0.2, 2.0, B)
+    nlay = None
+    if rng.random() < 0.3 and L > 3:
+        nlay = rng.integers(2, L + 1, B).astype(np.int32)
+    P = int(rng.integers(1, 40))
+    per = np.sort(rng.uniform(3.0, 150.0, P)).astype(np.float32)
+    if rng.random() < 0.5:
+        per = np.linspace(rng.uniform(4, 12), rng.uniform(40, 120), P).astype(np.float32)
+    team = int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64]))
+    _lib.lib().surfdisp_set_team(team)
+    c, u, st = forward.forward_batch(model, per, kind, nlay=nlay)
+    co, uo, so = cport.forward_batch(model, per, kind, nlay=nlay, nthreads=32)
+    rows = ((c > 0) == (co > 0)).all(axis=1)
+    ok = (co != 0) & rows[:, None]
+    ec = np.abs(c[ok] / co[ok] - 1) if ok.any() else np.zeros(1)
+    eu = np.abs(u[ok] / uo[ok] - 1) if ok.any() else np.zeros(1)
+    nstack += B; ncase += 1; npat += int((~rows).sum())
+    q = np.quantile(eu, 0.999) if eu.size > 1000 else eu.max()
+    if ec.max() > 2e-5 or q > 1e-4 or (~rows).mean() > 0.02 or not np.isfinite(c).all() or not np.isfinite(u).all():
+        bad_cases.append((L, B, kind, noise, mono, P, team, float(ec.max()), float(eu.max()), float(q), int((~rows).sum())))
+        if len(bad_cases) <= int(os.environ.get("SOAK_SAVE", "12")):
+            # keep only the offending stacks (largest errors) so the file stays small
+            e = np.zeros(c.shape); e[ok] = np.maximum(np.abs(c[ok] / co[ok] - 1), np.nan_to_num(np.abs(u[ok] / uo[ok] - 1), nan=9.0))
+            score = e.max(axis=1) + (~rows) * 10 + (~np.isfinite(u).all(axis=1)) * 5
+            idx = np.argsort(score)[-8:]
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"soak_fail_{len(bad_cases):02d}.npz"),
+                                model=model[idx], per=per, kind=kind, team=team,
+                                nlay=(nlay[idx] if nlay is not None else np.full(len(idx), L, np.int32)),
+                                c=c[idx], u=u[idx], co=co[idx], uo=uo[idx], st=st[idx], so=so[idx])
+    worst["c"] = max(worst["c"], float(ec.max())); worst["u"] = max(worst["u"], float(q))
+_lib.lib().surfdisp_set_team(0)
+print(f"soak: {ncase} cases, {nstack} stacks, zero-pattern mismatches {npat} stacks "
+      f"({npat / max(nstack, 1):.2e}), worst c {worst['c']:.2e}, worst U(99.9%) {worst['u']:.2e}")
+for b in bad_cases[:20]:
+    print("  flagged: L=%d B=%d kind=%d noise=%.2f mono=%s P=%d team=%d  c %.1e  Umax %.1e  U99.9 %.1e  pattern %d" % b)

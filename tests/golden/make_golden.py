@@ -92,6 +92,11 @@ def main():
     add("lvz_halfspace_L4", lvz, np.linspace(6, 80, 18))
     two = synth_models(4, 2, 7)
     add("two_layer", two, P20)
+    # thick rough stacks at short periods: the Rayleigh eigenfunction solutions grow by up to ~1e27
+    # between the effective half space and the surface (found by scripts/soak.py)
+    add("rough_thick_L6", synth_models(48, 6, 21, noise=0.2, monotone=False, total_thickness=400.), np.linspace(5, 40, 8))
+    add("rough_thick_L12", synth_models(48, 12, 22, noise=0.2, monotone=False, total_thickness=340.), np.linspace(4, 60, 10))
+    add("rough_thick_L22", synth_models(32, 22, 23, noise=0.2, monotone=False, total_thickness=400.), np.linspace(3.3, 50, 12))
 
     flat = {}
     for key, d in cases.items():
