@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pysurfinv_amd import _lib, forward
 np.set_printoptions(linewidth=200, precision=7)
-for f in sorted(glob.glob(os.path.join(ROOT, "scripts", "soakfail", "*.npz"))):
+for f in sorted(glob.glob(os.path.join(os.environ.get("SOAK_DIR", os.path.join(ROOT, "gpurun_out")), "soak_fail_*.npz"))):
     d = np.load(f); kind = int(d["kind"])
     out = []
     for wtol, atol, team in (("1.2e-3", "1e-6", int(d["team"])), ("1e-7", "1e-6", int(d["team"])), ("1e-7", "1e-6", 64), ("1e-7", "1e-6", 1)):
