@@ -12,6 +12,12 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
+# same trace with ONE batch in flight (what bench.py brackets with HIP events): kernel durations are
+# not stretched by the second stream's kernels sharing the machine
+export BENCH_IN_FLIGHT=1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_one" -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/trace_one.log" 2>&1
+echo "trace_one rc=$?"
+unset BENCH_IN_FLIGHT
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
 echo "pmc fetch rc=$?"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > "$OUT/pmc_write.log" 2>&1
