@@ -15,9 +15,10 @@ reference's ``MCinv._brownians()`` order (``models.py:240-253``): layers in dict
 order, list elements in order.
 
 Supported layer types (rules cited per class): Sediment, Crust, Mantle/OceanMantle, OceanWater,
-OceanSediment, OceanCrust, and the ReferenceMantle appended when ``Info.refLayer`` is set
-(``models.py:116,153-154``).  Cascadia-specific classes and ``Gauss``/thermal options are out of
-scope.
+OceanSediment, OceanCrust, OceanSedimentCascadia, the thermal OceanMantleHybrid (SURVEY.md 8f-4,
+``layers.py:297-363`` over ``thermseis.py``), and the ReferenceMantle appended when ``Info.refLayer``
+is set (``models.py:116,153-154``).  The Crust ``Gauss`` option is out of scope (it needs the
+un-vendored ``Triforce.mathPlus.gaussFun``).
 """
 from __future__ import annotations
 
@@ -106,7 +107,10 @@ class _Slot:
 
 class Model1DBatch:
     LAYER_TYPES = {"Sediment": "sed", "Crust": "crust", "Mantle": "mantle", "OceanMantle": "mantle",
-                   "OceanWater": "water", "OceanSediment": "osed", "OceanCrust": "ocrust"}
+                   "OceanWater": "water", "OceanSediment": "osed", "OceanCrust": "ocrust",
+                   "OceanSedimentCascadia": "osedc", "OceanMantleHybrid": "hybrid"}
+    GROUP = {"sed": "sediment", "osed": "sediment", "osedc": "sediment", "crust": "crust", "ocrust": "crust",
+             "mantle": "mantle", "hybrid": "mantle", "water": "water"}
 
     def __init__(self, setting: dict, device="cpu"):
         import torch
@@ -144,10 +148,24 @@ class Model1DBatch:
                         lay["Vs_scalar"] = True
                 elif k == "deg":
                     lay["deg"] = int(v)
+                elif k in ("ThermAge", "Tp") and kind == "hybrid":
+                    lay[k] = slot(v, f"{key}.{k}")
+                elif k == "Conversion" and kind == "hybrid":
+                    if v not in ("Ritzwoller", "Yamauchi"):
+                        raise ValueError(f"Invalid convertion model: {v}")       # layers.py:338
+                    lay[k] = v
                 elif k in ("Gauss",):
                     raise ValueError("Crust 'Gauss' option is out of scope")
-            if kind == "water":
+            if kind in ("water", "osedc"):
                 lay["Vs"] = []
+            if kind == "hybrid":
+                if "ThermAge" not in lay:
+                    raise KeyError("OceanMantleHybrid needs 'ThermAge'")
+                lay["deg"] = None                              # layers.py:341 calls _bspl(z, nBasis) only
+                groups = [self.GROUP[l["kind"]] == "crust" for l in self.layers]
+                runs = sum(1 for i, g in enumerate(groups) if g and (i == 0 or not groups[i - 1]))
+                if runs != 1:                                  # getCrustH, layers.py:304-310
+                    raise ValueError("OceanMantleHybrid: exactly one contiguous crust group must lie above it")
             self.layers.append(lay)
         self.spec = ParamSpec.from_entries(entries, names)
         self._basis = {}
@@ -171,7 +189,7 @@ class Model1DBatch:
             n_lo, n_hi = self._n_fine_from_H(lay, h_lo), self._n_fine_from_H(lay, h_hi)
             if int(n_lo) != int(n_hi) or float(h_lo) < H_LOWER * 4:      # also keeps every h > 0.01
                 return None
-            if lay["kind"] not in ("sed", "osed", "water") and float(h_lo) / max(int(n_lo), 1) < H_LOWER * 2:
+            if lay["kind"] not in ("sed", "osed", "osedc", "water") and float(h_lo) / max(int(n_lo), 1) < H_LOWER * 2:
                 return None
             sig.append(int(n_lo))
             zlo, zhi = zlo + h_lo, zhi + h_hi
@@ -180,9 +198,9 @@ class Model1DBatch:
     def _n_fine_from_H(self, lay, H):
         torch = self.torch
         kind = lay["kind"]
-        if kind in ("sed", "osed", "water"):
+        if kind in ("sed", "osed", "osedc", "water"):
             N = torch.ones_like(H, dtype=torch.int64)
-        elif kind in ("crust", "mantle"):
+        elif kind in ("crust", "mantle", "hybrid"):
             N = _n_fine_mantle(H)
         else:
             N = torch.clamp(torch.round(H / 2).to(torch.int64), 2, 10)
@@ -196,7 +214,40 @@ class Model1DBatch:
                                                     dtype=self.torch.float64, device=self.device)
         return self._basis[key]
 
-    def _layer_grid(self, lay, params, z_bottom, N):
+    def _hybrid_grid(self, lay, params, z_bottom, crust_h, N, H, t):
+        """OceanMantleHybrid (layers.py:297-363): thermal Vs of a half-space cooling model of age
+        ``ThermAge`` above the depth where melting starts, thermal Vs + B-spline perturbation below 1.7 x
+        that depth, a not-a-knot cubic spline through both parts in between; Qs from the pre-melting
+        anelasticity model."""
+        from . import thermseis as ts
+        torch = self.torch
+        z = t * H[:, None]
+        age_p = lay["ThermAge"].get(params)
+        age = age_p.clamp(min=1e-3)
+        Tp = lay["Tp"].get(params)[:, None] if "Tp" in lay else 1325.0
+        ther = ts.hscm(age, zdeps=crust_h[:, None] + z, Tp=Tp)
+        if lay.get("Conversion", "Ritzwoller") == "Yamauchi":
+            vs_th = ts.ruan(ther, period=1)[0]
+        else:
+            vs_th = ts.ritz_vs(ther)[0]
+        z_melt = ts.melt_start(age, crust_h)
+        coef = torch.stack([torch.zeros_like(age)] + [s.get(params) for s in lay["Vs"]], dim=1)
+        y2 = coef @ self._bspl(N, coef.shape[1], None) + vs_th
+        x_lo = z_melt[:, None]
+        x_hi = ((z_melt + crust_h) * 1.7 - crust_h)[:, None]
+        upper, lower = z < x_lo, z > x_hi
+        vs = ts.cubic_spline_through(z, torch.where(upper, vs_th, y2), upper | lower)
+        lay["zmelt_last"] = z_melt                      # the reference keeps it too (_debug_zMelt)
+        # _calOthers, layers.py:350-363
+        if self.info.get("lithoAgeQ", False) and self.info.get("lithoAge", None) is not None:
+            q_age = torch.full_like(age, float(self.info["lithoAge"]))
+        else:
+            q_age = age_p
+        ther_q = ts.hscm(q_age.clamp(min=1e-3), zdeps=z_bottom[:, None] + z)
+        qs = ts.ruan(ther_q, period=float(self.info.get("period", 1)))[1].clamp(max=5000.0)
+        return z, vs, vs * 1.76, 3.4268 + (vs - 4.5) / 4.5, qs, 1400. * torch.ones_like(vs)
+
+    def _layer_grid(self, lay, params, z_bottom, N, crust_h=None):
         """Grids (z[Bg,N+1] relative to the layer top, vs, vp, rho, qs, qp) for one layer type."""
         torch = self.torch
         Bg = params.shape[0]
@@ -209,6 +260,12 @@ class Model1DBatch:
         ones = torch.ones((Bg, N + 1), dtype=torch.float64, device=self.device)
         if kind == "water":                                # layers.py:187-199
             return z, 0 * ones, 1.475 * ones, 1.027 * ones, 10000. * ones, 57822. * ones
+        if kind == "hybrid":
+            return self._hybrid_grid(lay, params, z_bottom, crust_h, N, H, t)
+        if kind == "osedc":                                # OceanSedimentCascadia, layers.py:288-295
+            vs = ((0.02 * H ** 2 + 1.27 * H + 0.29 * 0.1) / (H + 0.29))[:, None] * ones
+            vp = vs * 1.23 + 1.28
+            return z, vs, vp, 0.541 + 0.3601 * vp, 80. * ones, 160. * ones
         coef = torch.stack([s.get(params) for s in lay["Vs"]], dim=1)      # [Bg, nb]
         nb = coef.shape[1]
         if kind in ("sed", "ocrust"):                      # layers.py:145-149, 218-222
@@ -247,9 +304,9 @@ class Model1DBatch:
         if lay.get("Hkey") == "BottomDepth":
             H = H - z_bottom
         kind = lay["kind"]
-        if kind in ("sed", "osed", "water"):
+        if kind in ("sed", "osed", "osedc", "water"):
             N = torch.ones_like(H, dtype=torch.int64)
-        elif kind in ("crust", "mantle"):
+        elif kind in ("crust", "mantle", "hybrid"):
             N = _n_fine_mantle(H)
         else:                                              # OceanCrust, layers.py:216-217
             N = torch.clamp(torch.round(H / 2).to(torch.int64), 2, 10)
@@ -289,14 +346,17 @@ class Model1DBatch:
             nrows = p.shape[0]
             zbot = torch.full((nrows,), z_start, dtype=torch.float64, device=self.device)
             cols = [[] for _ in range(6)]
+            crust_h = torch.zeros_like(zbot)
             for li, lay in enumerate(self.layers):
                 N = int(uniq[g, li].item())
                 if N < 0:
                     continue
-                z, vs, vp, rho, qs, qp = self._layer_grid(lay, p, zbot, N)
+                z, vs, vp, rho, qs, qp = self._layer_grid(lay, p, zbot, N, crust_h)
                 for c_, a in zip(cols, (z + zbot[:, None], vs, vp, rho, qs, qp)):
                     c_.append(a)
                 zbot = zbot + z[:, -1]
+                if self.GROUP[lay["kind"]] == "crust":
+                    crust_h = crust_h + z[:, -1]
             if ref_layer:                                  # ReferenceMantle, layers.py:267-284
                 vs0, vp0, rho0, qs0, qp0 = (cols[i][-1][:, -1:] for i in range(1, 6))
                 t = torch.linspace(0.0, 1.0, 21, dtype=torch.float64, device=self.device)[None, :]
@@ -332,6 +392,8 @@ class Model1DBatch:
         """(idesc int32, fdesc float64, L) for csrc/surfdisp_layers.hip, or None when the layer
         structure is not static.  Cached on the model's device."""
         if self._static_sig is None or len(self.layers) > 10:
+            return None
+        if any(lay["kind"] not in self.KIND_CODE for lay in self.layers):      # thermal layers: torch path
             return None
         if getattr(self, "_native_desc", None) is not None:
             return self._native_desc

@@ -80,3 +80,48 @@ def sens_kernel_pert(H, Vs, Vp=None, Rho=None, Qs=None, Grp=None, periods=range(
         out[name] = full
     out["c0"], out["u0"], out["status"] = c[0], u[0], st
     return out
+
+
+def sens_kernel_pert_batch(model, periods, wtype="R", nlay=None, lo=0.999, hi=1.001, chunk=256):
+    """Finite-difference Vs kernels of MANY stacks on the device (BASELINE configs[4]: "senskernel
+    sensitivity evaluation" of every model of a batch).
+
+    model: torch float32 [M, 5, L] rows (vp, vs, rho, h, 1/Qs) on a HIP device - explicit columns,
+    so only Vs is scaled (``_perturb`` with explicit Vp/Rho/Qs columns, senskernel.py:160-166);
+    periods: torch float32 [P] ascending.  Each stack contributes its unperturbed solve and 2L
+    perturbed ones, ``chunk`` stacks (= chunk*(2L+1) solves) per launch.
+    Returns dict(phv, grv: float32 [M, P, L] = (v(hi) - v(lo)) / 0.2 / h_i (senskernel.py:150), NaN
+    where a perturbed solve failed; c0, u0: [M, P]; status [M])."""
+    import torch
+    kind = {"R": 2, "L": 1}[wtype]
+    M, _, L = model.shape
+    P = periods.numel()
+    dev = model.device
+    # scale[j, i]: factor on layer i of variant j (0: none, 1..L: lo, L+1..2L: hi)
+    scale = torch.ones((2 * L + 1, L), dtype=torch.float32, device=dev)
+    ar = torch.arange(L, device=dev)
+    scale[1 + ar, ar] = lo
+    scale[1 + L + ar, ar] = hi
+    out = {k: torch.empty((M, P, L), dtype=torch.float32, device=dev) for k in ("phv", "grv")}
+    out["c0"] = torch.empty((M, P), dtype=torch.float32, device=dev)
+    out["u0"] = torch.empty((M, P), dtype=torch.float32, device=dev)
+    out["status"] = torch.empty(M, dtype=torch.int32, device=dev)
+    V = 2 * L + 1
+    plan = None
+    for a in range(0, M, chunk):
+        m = model[a:a + chunk]
+        n = m.shape[0]
+        big = m[:, None].expand(n, V, 5, L).clone()
+        big[:, :, 1, :] *= scale[None]
+        nl = None if nlay is None else nlay[a:a + chunk].repeat_interleave(V)
+        if plan is None or plan.B != n * V:
+            plan = _forward.BatchPlan(n * V, L, P, device=dev)
+        c, u, st = plan.run(big.reshape(n * V, 5, L), periods, kind=kind, nlay=nl)
+        c, u, st = c.view(n, V, P), u.view(n, V, P), st.view(n, V)
+        bad = ((st[:, 1:1 + L] != 0) | (st[:, 1 + L:] != 0))[:, None, :]           # [n, 1, L]
+        h = m[:, 3, :][:, None, :]
+        for name, v in (("phv", c), ("grv", u)):
+            k = (v[:, 1 + L:] - v[:, 1:1 + L]).transpose(1, 2) / 0.2 / h         # [n, P, L]
+            out[name][a:a + n] = torch.where(bad | (h <= 0), torch.full_like(k, float("nan")), k)
+        out["c0"][a:a + n], out["u0"][a:a + n], out["status"][a:a + n] = c[:, 0], u[:, 0], st[:, 0]
+    return out

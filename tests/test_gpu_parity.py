@@ -248,6 +248,29 @@ def test_sensitivity_kernels_match_oracle_finite_differences(hip, eus):
     assert np.abs(k["phv"][:, thick] - kref[:, thick]).max() < 2e-2 * scale
 
 
+def test_batched_device_sensitivity_kernels(hip):
+    """sens_kernel_pert_batch (many stacks, built and differenced on the device) = the one-stack host
+    version, stack by stack, for both wave types."""
+    import torch
+    from pysurfinv_amd import senskernel, synth
+    M, L = 5, 12
+    model = synth.synth_models(M, L, seed=9)
+    periods = list(range(20, 101, 10))
+    per = torch.as_tensor(np.asarray(periods, np.float32)).cuda()
+    for wtype in ("R", "L"):
+        out = senskernel.sens_kernel_pert_batch(torch.from_numpy(model).cuda(), per, wtype=wtype, chunk=2)
+        for i in range(M):
+            m = model[i].astype(np.float64)
+            k = senskernel.sens_kernel_pert(m[3], m[1], m[0], m[2], 1.0 / m[4], periods=periods, wtype=wtype)
+            for name in ("phv", "grv"):
+                a, b = out[name][i].cpu().numpy(), k[name]
+                assert a.shape == b.shape == (len(periods), L)
+                # same HIP solves; the only difference is fp32 vs fp64 differencing of the outputs
+                assert np.nanmax(np.abs(a - b)) <= 1e-5 * max(1.0, np.nanmax(np.abs(b))), (wtype, name, i)
+            assert np.array_equal(out["c0"][i].cpu().numpy(), k["c0"])
+    assert int(out["status"].abs().sum()) == 0
+
+
 def test_device_entry_is_graph_capturable(hip):
     """surfdisp_forward_batch_device allocates nothing and never synchronises: the three kernels +
     finish can be captured in a HIP graph and replayed (launch-bound inner loops of the Metropolis
