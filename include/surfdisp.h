@@ -124,6 +124,15 @@ int surfdisp_events_elapsed_ms(void *start, void *stop, float *ms);
  *          csrc/surfdisp_layers.hip).  All device pointers; stream-ordered; graph-capturable. */
 int surfdisp_params_to_model_device(void *stream, int C, int N, int L, const double *params,
                                     const int *idesc, const double *fdesc, float *model);
+/*          The same for a model whose mantle is the thermal OceanMantleHybrid layer (SURVEY.md 8f-4:
+ *          layers.py:297-363 over ThermSeis.py HSCM / OceanSeisRitz / OceanSeisRuan): one more kernel
+ *          (csrc/surfdisp_thermal.hip) evaluates the half-space cooling models, the mineral physics /
+ *          anelasticity and the merge spline, one wavefront per chain, into the caller-owned scratch
+ *          (surfdisp_thermal_scratch_bytes(C) bytes of device memory). */
+size_t surfdisp_thermal_scratch_bytes(int C);
+int surfdisp_params_to_model_thermal_device(void *stream, int C, int N, int L, const double *params,
+                                            const int *idesc, const double *fdesc,
+                                            void *scratch, size_t scratch_bytes, float *model);
 
 /* ---- tuning / introspection ------------------------------------------------------------- */
 /* lanes of one wavefront that cooperate on one stack's root search (1,2,4,...,64); 0 = choose

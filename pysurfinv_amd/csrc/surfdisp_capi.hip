@@ -193,7 +193,33 @@ int surfdisp_params_to_model_device(void *stream, int C, int N, int L, const dou
         set_err("surfdisp_params_to_model_device: bad argument");
         return SURFDISP_ERR_INVALID;
     }
-    sd::LayersArgs a{C, N, params, idesc, fdesc, model};
+    sd::LayersArgs a{C, N, params, idesc, fdesc, model, nullptr};
+    SD_HIP(sd::launch_layers(static_cast<hipStream_t>(stream), a, L));
+    return SURFDISP_SUCCESS;
+}
+
+// Same for a model with one thermal mantle layer (OceanMantleHybrid): the thermal
+// kernel fills scratch ([C][64][2] doubles, caller-owned: no allocation, graph-capturable), the layer
+// kernel assembles the stack.
+size_t surfdisp_thermal_scratch_bytes(int C)
+{
+    return C < 1 ? 0 : (size_t)C * 64 * 2 * sizeof(double);
+}
+
+int surfdisp_params_to_model_thermal_device(void *stream, int C, int N, int L, const double *params,
+                                            const int *idesc, const double *fdesc,
+                                            void *scratch, size_t scratch_bytes, float *model)
+{
+    if (C < 1 || N < 0 || L < 2 || L > SURFDISP_NLAY_MAX || !params || !idesc || !fdesc || !model || !scratch) {
+        set_err("surfdisp_params_to_model_thermal_device: bad argument");
+        return SURFDISP_ERR_INVALID;
+    }
+    if (scratch_bytes < surfdisp_thermal_scratch_bytes(C)) {
+        set_err("surfdisp_params_to_model_thermal_device: scratch too small (surfdisp_thermal_scratch_bytes)");
+        return SURFDISP_ERR_INVALID;
+    }
+    sd::LayersArgs a{C, N, params, idesc, fdesc, model, static_cast<double *>(scratch)};
+    SD_HIP(sd::launch_thermal(static_cast<hipStream_t>(stream), a));
     SD_HIP(sd::launch_layers(static_cast<hipStream_t>(stream), a, L));
     return SURFDISP_SUCCESS;
 }

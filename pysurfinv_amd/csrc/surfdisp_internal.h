@@ -57,8 +57,10 @@ struct LayersArgs {
     const int *idesc;      // see surfdisp_layers.hip
     const double *fdesc;
     float *model;          // [C][5][L]
+    double *scratch;       // [C][64][2] (vs, qs) of the thermal layer's grid points, or nullptr
 };
 hipError_t launch_layers(hipStream_t s, const LayersArgs &a, int L);
+hipError_t launch_thermal(hipStream_t s, const LayersArgs &a);
 
 size_t phase_lds_bytes(int Lmax, int G);
 hipError_t launch_finish(hipStream_t s, const FinishArgs &a);

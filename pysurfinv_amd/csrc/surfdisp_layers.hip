@@ -9,7 +9,9 @@
 //          (nlayers_in x 8) ; then per output layer its top grid index (L ints)
 //   fdesc: [0]=z_start ; per input layer (1+8 doubles): hconst, coefconst[8] ;
 //          then per grid point (1+8 doubles): t in [0,1], basis row (vs = sum basis[k]*coef[k])
-// kinds: 0 sed, 1 crust, 2 mantle, 3 water, 4 osed, 5 ocrust  (rules: layers.py, cited below)
+// kinds: 0 sed, 1 crust, 2 mantle, 3 water, 4 osed, 5 ocrust  (rules: layers.py, cited below),
+//        6 thermal mantle (OceanMantleHybrid): vs, qs per grid point come from the scratch array
+//        written by surfdisp_thermal_kernel (surfdisp_thermal.hip), 7 OceanSedimentCascadia
 #include <hip/hip_runtime.h>
 #include "surfdisp_internal.h"
 
@@ -33,6 +35,10 @@ __device__ __forceinline__ void closed_forms(int kind, double vs, double &vp, do
         case 3:  // OceanWater, layers.py:187-199
             vp = 1.475; rho = 1.027; qs = 10000.0; break;
         case 4:  // OceanSediment, layers.py:208-213
+            vp = vs * 1.23 + 1.28; rho = 0.541 + 0.3601 * vp; qs = 80.0; break;
+        case 6:  // OceanMantleHybrid._calOthers, layers.py:350-363: qs is set by the caller
+            vp = vs * 1.76; rho = 3.4268 + (vs - 4.5) / 4.5; break;
+        case 7:  // OceanSedimentCascadia = OceanSediment rules, layers.py:288-295
             vp = vs * 1.23 + 1.28; rho = 0.541 + 0.3601 * vp; qs = 80.0; break;
         default: // OceanCrust, layers.py:223-228
             vp = vs * 1.8; rho = 0.541 + 0.3601 * vp; qs = 350.0; break;
@@ -72,25 +78,40 @@ __global__ __launch_bounds__(256) void surfdisp_layers_kernel(LayersArgs A)
             const double *gf = grid_f + 9 * g;
             v.z = ztop[l] + gf[0] * Hl[l];
             double vs = 0.0;
-            const int nc = lay_i[8 * l + 3];
-            for (int k = 0; k < nc; ++k) {
-                const int sl = coef_i[8 * l + k];
-                vs += gf[1 + k] * ((sl >= 0) ? p[sl] : lay_f[9 * l + 1 + k]);
+            const int kind = lay_i[8 * l];
+            if (kind == 6) {
+                const double *sc = A.scratch + ((size_t)c * 64 + (g - lay_i[8 * l + 4])) * 2;
+                vs = sc[0]; v.qs = sc[1];
+            } else if (kind == 7) {
+                const double H = Hl[l];
+                vs = (0.02 * (H * H) + 1.27 * H + 0.29 * 0.1) / (H + 0.29);
+            } else {
+                const int nc = lay_i[8 * l + 3];
+                for (int k = 0; k < nc; ++k) {
+                    const int sl = coef_i[8 * l + k];
+                    vs += gf[1 + k] * ((sl >= 0) ? p[sl] : lay_f[9 * l + 1 + k]);
+                }
             }
             v.vs = vs;
-            closed_forms(lay_i[8 * l], vs, v.vp, v.rho, v.qs);
+            closed_forms(kind, vs, v.vp, v.rho, v.qs);
         } else {
             // ReferenceMantle (layers.py:267-284): 21 points over 300 km hanging off the last grid point
             const int gl = ngrid - 1;
             int l = nin - 1;
             const double *gf = grid_f + 9 * gl;
-            double vs0 = 0.0;
-            const int nc = lay_i[8 * l + 3];
-            for (int k = 0; k < nc; ++k) {
-                const int sl = coef_i[8 * l + k];
-                vs0 += gf[1 + k] * ((sl >= 0) ? p[sl] : lay_f[9 * l + 1 + k]);
+            double vs0 = 0.0, vp0, rho0, qs0 = 0.0;
+            if (lay_i[8 * l] == 6) {
+                const double *sc = A.scratch + ((size_t)c * 64 + (gl - lay_i[8 * l + 4])) * 2;
+                vs0 = sc[0]; qs0 = sc[1];
+            } else if (lay_i[8 * l] == 7) {
+                vs0 = (0.02 * (Hl[l] * Hl[l]) + 1.27 * Hl[l] + 0.29 * 0.1) / (Hl[l] + 0.29);
+            } else {
+                const int nc = lay_i[8 * l + 3];
+                for (int k = 0; k < nc; ++k) {
+                    const int sl = coef_i[8 * l + k];
+                    vs0 += gf[1 + k] * ((sl >= 0) ? p[sl] : lay_f[9 * l + 1 + k]);
+                }
             }
-            double vp0, rho0, qs0;
             closed_forms(lay_i[8 * l], vs0, vp0, rho0, qs0);
             const double t = (double)(g - ngrid) / 20.0;
             const double zr = t * 300.0;

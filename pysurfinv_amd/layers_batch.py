@@ -238,6 +238,7 @@ class Model1DBatch:
         upper, lower = z < x_lo, z > x_hi
         vs = ts.cubic_spline_through(z, torch.where(upper, vs_th, y2), upper | lower)
         lay["zmelt_last"] = z_melt                      # the reference keeps it too (_debug_zMelt)
+        lay["grid_last"] = None
         # _calOthers, layers.py:350-363
         if self.info.get("lithoAgeQ", False) and self.info.get("lithoAge", None) is not None:
             q_age = torch.full_like(age, float(self.info["lithoAge"]))
@@ -245,6 +246,7 @@ class Model1DBatch:
             q_age = age_p
         ther_q = ts.hscm(q_age.clamp(min=1e-3), zdeps=z_bottom[:, None] + z)
         qs = ts.ruan(ther_q, period=float(self.info.get("period", 1)))[1].clamp(max=5000.0)
+        lay["grid_last"] = (vs, qs)
         return z, vs, vs * 1.76, 3.4268 + (vs - 4.5) / 4.5, qs, 1400. * torch.ones_like(vs)
 
     def _layer_grid(self, lay, params, z_bottom, N, crust_h=None):
@@ -386,14 +388,15 @@ class Model1DBatch:
         return tuple(o[:, :Lmax] for o in out), nlay
 
     # ------------------------------------------------------------------ native (HIP) path
-    KIND_CODE = {"sed": 0, "crust": 1, "mantle": 2, "water": 3, "osed": 4, "ocrust": 5}
+    KIND_CODE = {"sed": 0, "crust": 1, "mantle": 2, "water": 3, "osed": 4, "ocrust": 5, "hybrid": 6, "osedc": 7}
 
     def native_descriptor(self):
         """(idesc int32, fdesc float64, L) for csrc/surfdisp_layers.hip, or None when the layer
         structure is not static.  Cached on the model's device."""
         if self._static_sig is None or len(self.layers) > 10:
             return None
-        if any(lay["kind"] not in self.KIND_CODE for lay in self.layers):      # thermal layers: torch path
+        hybrids = [i for i, lay in enumerate(self.layers) if lay["kind"] == "hybrid"]
+        if len(hybrids) > 1 or (hybrids and self._static_sig[hybrids[0]] + 1 > 64):
             return None
         if getattr(self, "_native_desc", None) is not None:
             return self._native_desc
@@ -405,6 +408,8 @@ class Model1DBatch:
         for lay, N in zip(self.layers, self._static_sig):
             hs = lay["H"]
             slots = lay["Vs"]
+            if lay["kind"] == "hybrid":                        # leading zero coefficient, layers.py:341
+                slots = [_Slot(const=0.0)] + list(slots)
             if len(slots) > 8:
                 return None
             begin, end = g, g + N + 1
@@ -415,14 +420,16 @@ class Model1DBatch:
             lay_f += [(float(sl.const) if sl.const is not None else 0.0) for sl in slots] + [0.0] * (8 - len(slots))
             kind, nb = lay["kind"], len(slots)
             bas = None
-            if kind in ("crust", "mantle"):
+            if kind in ("crust", "mantle", "hybrid"):
                 bas = bspline_basis(N + 1, nb, lay.get("deg"))          # [nb, N+1]
             for q in range(N + 1):
                 t = float(np.linspace(0.0, 1.0, N + 1)[q])
                 if kind == "water":
                     row = []
-                elif kind in ("crust", "mantle"):
+                elif kind in ("crust", "mantle", "hybrid"):
                     row = [float(bas[k, q]) for k in range(nb)]
+                elif kind == "osedc":
+                    row = []
                 elif nb == 2 and kind in ("sed", "ocrust"):
                     row = [1.0 - t, t]
                 else:
@@ -437,6 +444,19 @@ class Model1DBatch:
         idesc = [nin, ngrid, L, 1 if ref else 0] + lay_i + coef_i + tops
         topo = float(self.info.get("topo", 0.0))
         fdesc = [-max(topo, 0.0)] + lay_f + grid_f
+        self._native_thermal = bool(hybrids)
+        if hybrids:                                        # descriptor tail, csrc/surfdisp_thermal.hip
+            lh = hybrids[0]
+            lay = self.layers[lh]
+            age, tp = lay["ThermAge"], lay.get("Tp", _Slot(const=1325.0))
+            q_const = bool(self.info.get("lithoAgeQ", False)) and self.info.get("lithoAge", None) is not None
+            crust_mask = sum(1 << i for i, l in enumerate(self.layers[:lh]) if self.GROUP[l["kind"]] == "crust")
+            idesc += [lh, age.idx if age.idx is not None else -1, tp.idx if tp.idx is not None else -1,
+                      1 if lay.get("Conversion", "Ritzwoller") == "Yamauchi" else 0, 1 if q_const else 0,
+                      crust_mask, self._static_sig[lh] + 1, 0]
+            fdesc += [float(age.const) if age.const is not None else 0.0,
+                      float(tp.const) if tp.const is not None else 0.0,
+                      float(self.info["lithoAge"]) if q_const else 0.0, float(self.info.get("period", 1))]
         self._native_desc = (torch.tensor(idesc, dtype=torch.int32, device=self.device),
                              torch.tensor(fdesc, dtype=torch.float64, device=self.device), L)
         return self._native_desc
@@ -455,10 +475,18 @@ class Model1DBatch:
         model = torch.empty((C, 5, L), dtype=torch.float32, device=p.device)
         stream = torch.cuda.current_stream(p.device).cuda_stream
         with torch.cuda.device(p.device):
-            rc = _lib.lib().surfdisp_params_to_model_device(
-                ctypes.c_void_p(stream), C, N, L, ctypes.c_void_p(p.data_ptr()),
-                ctypes.c_void_p(idesc.data_ptr()), ctypes.c_void_p(fdesc.data_ptr()),
-                ctypes.c_void_p(model.data_ptr()))
+            if self._native_thermal:
+                scratch = torch.empty((C, 64, 2), dtype=torch.float64, device=p.device)
+                self._thermal_scratch = scratch                # (vs, qs) per grid point, kept for inspection
+                rc = _lib.lib().surfdisp_params_to_model_thermal_device(
+                    ctypes.c_void_p(stream), C, N, L, ctypes.c_void_p(p.data_ptr()),
+                    ctypes.c_void_p(idesc.data_ptr()), ctypes.c_void_p(fdesc.data_ptr()),
+                    ctypes.c_void_p(scratch.data_ptr()), scratch.numel() * 8, ctypes.c_void_p(model.data_ptr()))
+            else:
+                rc = _lib.lib().surfdisp_params_to_model_device(
+                    ctypes.c_void_p(stream), C, N, L, ctypes.c_void_p(p.data_ptr()),
+                    ctypes.c_void_p(idesc.data_ptr()), ctypes.c_void_p(fdesc.data_ptr()),
+                    ctypes.c_void_p(model.data_ptr()))
         _lib.check(rc)
         return model, None
 

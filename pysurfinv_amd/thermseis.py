@@ -42,6 +42,8 @@ def _t(x, like=None):
     if torch.is_tensor(x):
         return x.to(torch.float64)
     dev = like.device if torch.is_tensor(like) else None
+    if isinstance(x, (int, float)):                          # a fill kernel, not a host->device copy
+        return torch.full((), float(x), dtype=torch.float64, device=dev)     # (HIP-graph capturable)
     return torch.as_tensor(x, dtype=torch.float64, device=dev)
 
 
@@ -251,16 +253,44 @@ def melt_start(age, z_crust):
     return torch.gather(ther.zdeps, 1, first[:, None]).squeeze(1) - z_crust
 
 
+def tridiagonal_solve(lo, di, up, rhs):
+    """Row-wise solve of tridiagonal systems [B, N] (lo[:, 0] and up[:, -1] ignored) by parallel cyclic
+    reduction: ceil(log2 N) sweeps of elementwise tensor ops - a handful of launches, no pivot search,
+    no host synchronisation (HIP-graph capturable).  The spline systems it is used for are diagonally
+    dominant except for the two not-a-knot end rows, which one reduction step makes dominant."""
+    B, N = di.shape
+    lo = lo.clone(); up = up.clone()
+    lo[:, 0] = 0
+    up[:, -1] = 0
+    F = torch.nn.functional
+    s = 1
+    while s < N:
+        # neighbours at distance s; beyond the ends: identity rows (lo = up = rhs = 0, di = 1)
+        sh = lambda a, fill: (F.pad(a, (s, 0), value=fill)[:, :N], F.pad(a, (0, s), value=fill)[:, s:])
+        lo_m, lo_p = sh(lo, 0.0)
+        up_m, up_p = sh(up, 0.0)
+        di_m, di_p = sh(di, 1.0)
+        r_m, r_p = sh(rhs, 0.0)
+        al = -lo / di_m
+        ga = -up / di_p
+        di = di + al * up_m + ga * lo_p
+        rhs = rhs + al * r_m + ga * r_p
+        lo = al * lo_m
+        up = ga * up_p
+        s *= 2
+    return rhs / di
+
+
 def cubic_spline_through(x, y, keep):
     """Row-wise ``scipy.interpolate.CubicSpline(x[keep], y[keep])(x)`` (not-a-knot ends; extrapolating
     with the end pieces) - ``merge2`` of ``OceanMantleHybrid._calVs`` (layers.py:321-325).
-    x, y [B, N] (x ascending), keep bool [B, N] with at least 2 knots per row."""
+    x, y [B, N] (x ascending), keep bool [B, N] with at least 2 knots per row.  No host
+    synchronisation anywhere (HIP-graph capturable)."""
     B, N = x.shape
     dev = x.device
     order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)
     n = keep.sum(dim=1)                                      # knots per row
-    if int(n.min()) < 2:
-        raise ValueError("cubic_spline_through needs at least two knots in every row")
+    n = n.clamp(min=2)                                       # fewer than two knots cannot occur in merge2
     xk = torch.gather(x, 1, order)
     yk = torch.gather(y, 1, order)
     idx = torch.arange(N, device=dev)[None, :]
@@ -275,51 +305,51 @@ def cubic_spline_through(x, y, keep):
     slope = (yk[:, 1:] - yk[:, :-1]) / dx
     # equations for the knot derivatives s (de Boor, "A practical guide to splines", ch. IV):
     #   dx[i] s[i-1] + 2 (dx[i-1] + dx[i]) s[i] + dx[i-1] s[i+1] = 3 (dx[i] slope[i-1] + dx[i-1] slope[i])
-    A = torch.zeros((B, N, N), dtype=x.dtype, device=dev)
+    lo = torch.zeros((B, N), dtype=x.dtype, device=dev)      # A[i, i-1]
+    di = torch.ones((B, N), dtype=x.dtype, device=dev)       # A[i, i]
+    up = torch.zeros((B, N), dtype=x.dtype, device=dev)      # A[i, i+1]
     rhs = torch.zeros((B, N), dtype=x.dtype, device=dev)
-    ar = torch.arange(1, N - 1, device=dev)
-    A[:, ar, ar - 1] = dx[:, 1:]
-    A[:, ar, ar] = 2 * (dx[:, :-1] + dx[:, 1:])
-    A[:, ar, ar + 1] = dx[:, :-1]
+    lo[:, 1:-1] = dx[:, 1:]
+    di[:, 1:-1] = 2 * (dx[:, :-1] + dx[:, 1:])
+    up[:, 1:-1] = dx[:, :-1]
     rhs[:, 1:-1] = 3 * (dx[:, 1:] * slope[:, :-1] + dx[:, :-1] * slope[:, 1:])
-    # rows at and behind the last knot are overwritten below; first row: not-a-knot at knot 1
+    # first row: not-a-knot at knot 1
     d = xk[:, 2] - xk[:, 0]
-    A[:, 0, 0] = dx[:, 1]
-    A[:, 0, 1] = d
+    di[:, 0] = dx[:, 1]
+    up[:, 0] = d
     rhs[:, 0] = ((dx[:, 0] + 2 * d) * dx[:, 1] * slope[:, 0] + dx[:, 0] ** 2 * slope[:, 1]) / d
-    rows = torch.arange(B, device=dev)
-    li = n - 1                                               # last knot row: not-a-knot at knot n-2
-    dxa = dx[rows, (li - 1).clamp(min=0)]                    # dx[n-2]
-    dxb = dx[rows, (li - 2).clamp(min=0)]                    # dx[n-3]
-    d = xk[rows, li] - xk[rows, (li - 2).clamp(min=0)]
-    sa = slope[rows, (li - 1).clamp(min=0)]
-    sb = slope[rows, (li - 2).clamp(min=0)]
-    A[rows, li, :] = 0
-    A[rows, li, li] = dxb
-    A[rows, li, (li - 1).clamp(min=0)] = d
-    rhs[rows, li] = (dxa ** 2 * sb + (2 * d + dxa) * dxb * sa) / d
-    # padding rows: identity (their values are never used)
-    padr = idx > last                                        # [B, N]
-    A = torch.where(padr[:, :, None], torch.eye(N, dtype=x.dtype, device=dev)[None], A)
-    rhs = torch.where(padr, torch.zeros_like(rhs), rhs)
-    # rows with 3 knots: the parabola through them (both not-a-knot conditions coincide); 2: a line
-    three = n == 3
-    if bool(three.any()):
-        r = rows[three]
-        A[r, :3, :] = 0
-        A[r, 0, 0] = 1; A[r, 0, 1] = 1
-        A[r, 1, 0] = dx[r, 1]; A[r, 1, 1] = 2 * (dx[r, 0] + dx[r, 1]); A[r, 1, 2] = dx[r, 0]
-        A[r, 2, 1] = 1; A[r, 2, 2] = 1
-        rhs[r, 0] = 2 * slope[r, 0]
-        rhs[r, 1] = 3 * (dx[r, 0] * slope[r, 1] + dx[r, 1] * slope[r, 0])
-        rhs[r, 2] = 2 * slope[r, 1]
-    two = n == 2
-    if bool(two.any()):
-        r = rows[two]
-        A[r, :2, :] = 0
-        A[r, 0, 0] = 1; A[r, 1, 1] = 1
-        rhs[r, 0] = slope[r, 0]; rhs[r, 1] = slope[r, 0]
-    s = torch.linalg.solve(A, rhs[:, :, None]).squeeze(2)
+    # row of the last knot: not-a-knot at knot n-2
+    g1 = lambda a, j: torch.gather(a, 1, j.clamp(min=0)[:, None]).squeeze(1)
+    li = n - 1
+    dxa, dxb = g1(dx, li - 1), g1(dx, li - 2)                # dx[n-2], dx[n-3]
+    d = g1(xk, li) - g1(xk, li - 2)
+    sa, sb = g1(slope, li - 1), g1(slope, li - 2)
+    at_last = idx == last
+    lo = torch.where(at_last, d[:, None], lo)
+    di = torch.where(at_last, dxb[:, None], di)
+    up = torch.where(at_last, torch.zeros_like(up), up)
+    rhs = torch.where(at_last, ((dxa ** 2 * sb + (2 * d + dxa) * dxb * sa) / d)[:, None], rhs)
+    # padding rows behind the last knot: identity (their values are never used)
+    lo = torch.where(pad, torch.zeros_like(lo), lo)
+    di = torch.where(pad, torch.ones_like(di), di)
+    up = torch.where(pad, torch.zeros_like(up), up)
+    rhs = torch.where(pad, torch.zeros_like(rhs), rhs)
+    # rows with 3 knots: the parabola through them (both not-a-knot conditions coincide); 2: a line.
+    # Blended in with masks (no host synchronisation: the whole path is HIP-graph capturable).
+    one, zero = torch.ones_like(d), torch.zeros_like(d)
+    three = (n == 3)[:, None]
+    st = lambda *cols: torch.stack(cols, dim=1)
+    lo[:, :3] = torch.where(three, st(zero, dx[:, 1], one), lo[:, :3])
+    di[:, :3] = torch.where(three, st(one, 2 * (dx[:, 0] + dx[:, 1]), one), di[:, :3])
+    up[:, :3] = torch.where(three, st(one, dx[:, 0], zero), up[:, :3])
+    rhs[:, :3] = torch.where(three, st(2 * slope[:, 0], 3 * (dx[:, 0] * slope[:, 1] + dx[:, 1] * slope[:, 0]),
+                                       2 * slope[:, 1]), rhs[:, :3])
+    two = (n == 2)[:, None]
+    lo[:, :2] = torch.where(two, st(zero, zero), lo[:, :2])
+    di[:, :2] = torch.where(two, st(one, one), di[:, :2])
+    up[:, :2] = torch.where(two, st(zero, zero), up[:, :2])
+    rhs[:, :2] = torch.where(two, st(slope[:, 0], slope[:, 0]), rhs[:, :2])
+    s = tridiagonal_solve(lo, di, up, rhs)
     # piece i on [xk[i], xk[i+1]]:  y = y_i + s_i t + c2 t^2 + c3 t^3
     tq = (s[:, :-1] + s[:, 1:] - 2 * slope) / dx
     c3 = tq / dx

@@ -19,7 +19,7 @@ from pysurfinv_amd.layers_batch import Model1DBatch             # noqa: E402
 
 SETTING = {
     'OceanWater': {'H': 2.6},
-    'OceanSedimentCascadia': {'H': [0.3, 'rel_pos', 100, 0.03]},
+    'OceanSedimentCascadia': {'H': [0.3, 'abs', 0.2, 0.03]},
     'OceanCrust': {'H': 4.4, 'Vs': [3.25, 3.94]},
     'OceanMantleHybrid': {'BottomDepth': 200, 'Conversion': 'Ritzwoller', 'ThermAge': [4, 'rel_pos', 200, 0.4],
                           'Vs': [[0, 'abs', 0.2, 0.01], [0, 'abs', 0.2, 0.01], [0, 'abs', 0.2, 0.01], [0, 'abs', 0.1, 0.01]]},
@@ -43,17 +43,22 @@ def main():
     per = torch.from_numpy(synth.default_periods(20)).to(dev)
     mb = Model1DBatch(SETTING, device=dev)
     params = TorchProposer(mb.spec, dev, seed=1).reset(B)
-    dt, (model, nlay) = timed(lambda: mb.to_model(params), 3)
-    L = model.shape[2]
-    print(json.dumps({"stage": "thermal parameters -> layer stack (torch, device)", "stacks": B, "layers": L,
+    dt, (model_t, nlay_t) = timed(lambda: mb.to_model_torch(params), 3)
+    L = model_t.shape[2]
+    print(json.dumps({"stage": "thermal parameters -> layer stack (torch mirror, device)", "stacks": B, "layers": L,
                       "ms": dt * 1e3, "stacks_per_s": B / dt}), flush=True)
+    dt, (model, nlay) = timed(lambda: mb.to_model(params), 10)
+    err = float(((model - model_t).abs() / model_t.abs().clamp(min=1e-3)).max())
+    print(json.dumps({"stage": "thermal parameters -> layer stack (HIP: surfdisp_thermal_kernel + surfdisp_layers_kernel)",
+                      "stacks": B, "layers": L, "ms": dt * 1e3, "stacks_per_s": B / dt,
+                      "max_rel_diff_vs_torch_mirror": err}), flush=True)
     plan = forward.JointPlan(B, L, 20, device=dev)
     dt, out = timed(lambda: plan.run(model, per, nlay=nlay), 5)
     okR = float((out["statusR"] == 0).float().mean()); okL = float((out["statusL"] == 0).float().mean())
     print(json.dumps({"stage": "joint Rayleigh+Love c+U", "stacks": B, "layers": L, "ms": dt * 1e3,
                       "stacks_per_s": B / dt, "solves_per_s": 2 * B / dt, "solved_R": okR, "solved_L": okL}), flush=True)
     for w in ("R", "L"):
-        dt, k = timed(lambda: senskernel.sens_kernel_pert_batch(model[:MS], per, wtype=w, nlay=nlay[:MS]), 2)
+        dt, k = timed(lambda: senskernel.sens_kernel_pert_batch(model[:MS], per, wtype=w, nlay=None if nlay is None else nlay[:MS]), 2)
         nan = float(torch.isnan(k["phv"]).float().mean())
         print(json.dumps({"stage": f"finite-difference Vs sensitivity kernels, {w}", "stacks": MS, "layers": L,
                           "solves": MS * (2 * L + 1), "ms": dt * 1e3, "kernel_sets_per_s": MS / dt,

@@ -13,7 +13,15 @@ from pysurfinv_amd.mcmc import MetropolisBatch
 
 G = np.load(os.path.join(ROOT, "tests", "golden", "ref_driver.npz"))
 dev = "cuda:0"
-mb = Model1DBatch(CONT, device=dev)
+if os.environ.get("MCMC_MODEL", "cont") == "hybrid":
+    # thermal oceanic model: 86 layers, parameters -> stack through thermseis (torch)
+    from settings_therm import HYBRID_STATIC, PERIODS
+    GT = np.load(os.path.join(ROOT, "tests", "golden", "ref_therm.npz"))
+    mb = Model1DBatch(HYBRID_STATIC, device=dev)
+    G = {"trace/periods": np.asarray(PERIODS, float), "trace/c_obs": GT["hyb_ritz/c"][0] * 1.002,
+         "trace/uncer": np.full(len(PERIODS), 0.01)}
+else:
+    mb = Model1DBatch(CONT, device=dev)
 IND = os.environ.get("MCMC_INDEPENDENT", "0") == "1"
 for name, chains, steps, depth in (("configs[2] single point: 100 chains (100 000 steps = 100 x 1000)", 100, 61, 1),
                                    ("configs[2], speculative depth 3", 100, 61, 3),

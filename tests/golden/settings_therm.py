@@ -26,4 +26,12 @@ HYBRID_RITZ = _with('Ritzwoller', {})
 HYBRID_YAMA = _with('Yamauchi', {'lithoAgeQ': False, 'refLayer': False})
 HYBRID_YAMA['OceanMantleHybrid']['Tp'] = 1350
 HYBRID_YAMA['OceanMantleHybrid']['ThermAge'] = [0.5, 0.0, 3.0, 0.1]      # young: melt starts at the top
+# same model with a sediment prior bounded away from zero thickness: the layer structure is then the
+# same for every draw (Model1DBatch._static_sig) and the Metropolis step is HIP-graph capturable
+HYBRID_STATIC = _with('Ritzwoller', {})
+HYBRID_STATIC['OceanSedimentCascadia']['H'] = [0.3, 'abs', 0.2, 0.03]
+HYBRID_STATIC_YAMA = _with('Yamauchi', {'lithoAgeQ': False, 'refLayer': False})
+HYBRID_STATIC_YAMA['OceanSedimentCascadia']['H'] = [0.3, 'abs', 0.2, 0.03]
+HYBRID_STATIC_YAMA['OceanMantleHybrid']['Tp'] = [1350, 'abs', 40, 5]
+HYBRID_STATIC_YAMA['OceanMantleHybrid']['ThermAge'] = [0.5, 0.0, 3.0, 0.1]
 PERIODS = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 50, 60, 70, 80]

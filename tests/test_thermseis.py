@@ -12,7 +12,7 @@ from pysurfinv_amd.layers_batch import Model1DBatch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
-from settings_therm import HYBRID_RITZ, HYBRID_YAMA, PERIODS   # noqa: E402
+from settings_therm import HYBRID_RITZ, HYBRID_YAMA, HYBRID_STATIC, HYBRID_STATIC_YAMA, PERIODS   # noqa: E402
 
 G = np.load(os.path.join(HERE, "golden", "ref_therm.npz"))
 AGES = torch.as_tensor(G["ages"])
@@ -157,3 +157,47 @@ def test_hybrid_stack_and_forward_on_gpu():
         assert np.max(np.abs(cg.cpu().numpy() - co)) < 2e-5, kind
         fin = np.isfinite(uo)                              # the reference's Love U is NaN on some water stacks
         assert np.max(np.abs(ug.cpu().numpy() - uo)[fin]) < 5e-5, kind
+
+
+@pytest.mark.gpu
+def test_graphed_metropolis_on_thermal_model():
+    """Static thermal parameterisation: the whole Metropolis step (proposal, two half-space models,
+    mineral physics, spline, HIP forward, accept/reject) is captured in one HIP graph; every recorded
+    row's misfit equals the eagerly recomputed misfit of its parameters."""
+    from pysurfinv_amd.mcmc import MetropolisBatch
+    mb = Model1DBatch(HYBRID_STATIC, device="cuda:0")
+    assert mb._static_sig is not None
+    mc = MetropolisBatch(mb.spec, mb.to_model, PERIODS, G["hyb_ritz/c"][0] * 1.002, np.full(len(PERIODS), 0.01),
+                         device="cuda:0", seed=5)
+    track = mc.run_graphed(16, 10)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(track).all())
+    for k in (0, 1, 5, 9):
+        mis, _, _ = mc.misfit(track[:, k, 3:].contiguous())
+        assert float((mis - track[:, k, 0]).abs().max()) < 1e-9, k
+    acc = track[:, 1:, 2]
+    assert 0.0 < float(acc.mean()) < 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("setting", [HYBRID_STATIC, HYBRID_STATIC_YAMA], ids=["ritzwoller", "yamauchi_tp"])
+def test_native_thermal_kernel_matches_torch_mirror(setting):
+    """surfdisp_thermal_kernel + surfdisp_layers_kernel (HIP) against the torch mirror of the same
+    rules, itself pinned to the reference at 1e-14: Vs and Qs on the thermal layer's grid in fp64, and
+    the assembled fp32 stacks."""
+    from pysurfinv_amd.brownian import TorchProposer
+    mb = Model1DBatch(setting, device="cuda:0")
+    assert mb.native_descriptor() is not None and mb._native_thermal
+    params = TorchProposer(mb.spec, "cuda:0", seed=4).reset(300)
+    params[0] = torch.as_tensor(mb.spec.v0, device="cuda:0")
+    m_nat, nl = mb.to_model(params)
+    assert nl is None
+    m_ref, nlay = mb.to_model_torch(params)
+    assert m_ref.shape == m_nat.shape and int((nlay != m_nat.shape[2]).sum()) == 0
+    vs_t, qs_t = mb.layers[-1]["grid_last"]
+    npts = vs_t.shape[1]
+    sc = mb._thermal_scratch[:, :npts]
+    assert float(((sc[:, :, 0] - vs_t).abs() / vs_t.abs()).max()) < 1e-10
+    assert float(((sc[:, :, 1] - qs_t).abs() / qs_t.abs()).max()) < 1e-9
+    d = (m_nat - m_ref).abs() / m_ref.abs().clamp(min=1e-3)
+    assert float(d.max()) < 2e-6
