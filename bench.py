@@ -171,6 +171,18 @@ def main():
                 valu = tj.get("valu", {}).get("surfdisp_phase_kernel")
             except Exception:
                 traffic = None
+        recursion = None
+        rfile = os.path.join(ROOT, "profiles", "recursion_ceiling.json")
+        if os.path.exists(rfile):
+            try:
+                rj = json.load(open(rfile))
+                ev = rj["reference_evaluations_per_stack"] * B_PER_GPU / phase_s
+                recursion = {"achieved": ev, "peak": rj["ceiling_evaluations_per_s_no_divergence"],
+                             "unit": "secular-function evaluations/s", "frac": ev / rj["ceiling_evaluations_per_s_no_divergence"],
+                             "note": "reference-equivalent evaluations (oracle count per stack, committed) / live root-search "
+                                     "kernel time, against the bare recursion's measured rate (scripts/microbench/issue_rate.hip)"}
+            except Exception:
+                recursion = None
         line = {
             "metric": "layered-model dispersion forward solves/sec (20 periods)",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
@@ -192,6 +204,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "valu_pmc": valu,
+                         "recursion_ceiling": recursion,
                          "note": "algorithmic bytes = 360 B/solve x 65536 solves per launch; the path is "
                                  "VALU/transcendental-bound, not HBM-bound (SURVEY.md 8(d)); traffic and "
                                  "valu_pmc come from the committed rocprofv3 --pmc passes (profiles/)"},
