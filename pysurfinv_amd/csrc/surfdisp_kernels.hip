@@ -153,14 +153,16 @@ SD_HD __forceinline__ LayerV layer_at(const float *__restrict__ mdl, size_t fs, 
 }
 
 // ================================================================ secular functions (registers)
-// LDS working stack of one team: w[(f*Lcap + m)*S + slot], f = 0..5 (1/rho, b, rho, d, 1/a^2, 1/b^2)
-#define W_IR(m) wq[((0 * Lcap + (m)) * S)]    // 1/rho
-#define W_B(m) wq[((1 * Lcap + (m)) * S)]
-#define W_R(m) wq[((2 * Lcap + (m)) * S)]
-#define W_D(m) wq[((3 * Lcap + (m)) * S)]
-#define W_IA2(m) wq[((4 * Lcap + (m)) * S)]   // 1/a^2  (c-independent; saves a division per layer per trial)
-#define W_IB2(m) wq[((5 * Lcap + (m)) * S)]   // 1/b^2  (0 for a liquid layer)
+// LDS working stack of one team: w[(m*NFW + f)*S + slot], f = 0..5 (1/rho, b, rho, d, 1/a^2, 1/b^2):
+// the six values of a layer sit at compile-time offsets f*S from one address (ds_read immediates)
 constexpr int NFW = 6;
+#define W_AT(m, f) wq[(((m) * NFW + (f)) * S)]
+#define W_IR(m) W_AT(m, 0)    // 1/rho
+#define W_B(m) W_AT(m, 1)
+#define W_R(m) W_AT(m, 2)
+#define W_D(m) W_AT(m, 3)
+#define W_IA2(m) W_AT(m, 4)   // 1/a^2  (c-independent; saves a division per layer per trial)
+#define W_IB2(m) W_AT(m, 5)   // 1/b^2  (0 for a liquid layer)
 
 // ---- fast-but-tight fp32 helpers for the inner recursion --------------------------------------
 // The reference evaluates ~9 IEEE divisions, 2 sqrt and 2-4 libm calls per layer per trial
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
                                 for (int i = j; i < mm_frozen; i += G) {
 #pragma unroll
                                     for (int f = 0; f < NFW; ++f)
-                                        wq2[(f * Lcap + i) * S] = wq[(f * Lcap + i) * S];
+                                        wq2[(i * NFW + f) * S] = wq[(i * NFW + f) * S];
                                 }
                                 ell_pend = true; ell_k = k; ell_mm = mm_frozen; ell_c = croot; ell_T = T;
                                 solved = true;
