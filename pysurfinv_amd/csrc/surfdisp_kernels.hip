@@ -224,12 +224,12 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
     const float icsq = 1.0f / csq;
     float b1 = (start == 1) ? 1.0f : 0.0f, b2 = (start == 2) ? 1.0f : 0.0f,
           b3 = (start == 3) ? 1.0f : 0.0f, b4 = 0.0f, b5 = 0.0f;
-    // software pipeline: layer m+1's five LDS values are in flight while layer m is computed
-    float n_sv = W_B(0), n_rho = W_R(0), n_d = W_D(0), n_ia2 = W_IA2(0), n_ib2 = W_IB2(0), n_ir = W_IR(0);
-    for (int m = 0; m < mmax - 1; ++m) {
-        const float sv = n_sv, rho = n_rho, d = n_d, ia2 = n_ia2, ib2 = n_ib2, irho = n_ir;
-        n_sv = W_B(m + 1); n_rho = W_R(m + 1); n_d = W_D(m + 1); n_ia2 = W_IA2(m + 1); n_ib2 = W_IB2(m + 1);
-        n_ir = W_IR(m + 1);
+    // software pipeline: layer m+1's six LDS values are in flight while layer m is computed.  The loop
+    // is unrolled by two over alternating register sets (no rotation moves between iterations).
+    struct Lyr { float sv, rho, d, ia2, ib2, ir; };
+    auto load = [&](int m) -> Lyr { return {W_B(m), W_R(m), W_D(m), W_IA2(m), W_IB2(m), W_IR(m)}; };
+    auto step = [&](const Lyr &y) {
+        const float sv = y.sv, rho = y.rho, d = y.d, ia2 = y.ia2, ib2 = y.ib2, irho = y.ir;
         const float arga = fmaf(-csq, ia2, 1.0f);                    // 1 - c^2/a^2, surfa.f:211
         float ra = sqrt_hw(fabsf(arga));
         if (arga > 0.0f) ra = -ra;
@@ -237,7 +237,7 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         const float rhoc = rho * csq;
         if (!(fabsf(sv) > ACCUR)) {
             // liquid surface layer, surfa.f:216-251 (skipped entirely in the ellipticity passes)
-            if (start != 1) continue;
+            if (start != 1) return;
             const float pm = wd * ra;
             float sinpr, cosp;
             if (fabsf(ra) < ACCUR) { sinpr = wd; cosp = 1.0f; }
@@ -254,7 +254,7 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             const float n2 = rhoc * sinpr * b1;
             const float n5 = cosp * b5 - rhoc * sinpr * b4;
             b1 = n1; b2 = n2; b3 = 0.0f; b4 = 0.0f; b5 = n5;
-            continue;
+            return;
         }
         const float argb = fmaf(-csq, ib2, 1.0f);
         float rb = sqrt_hw(fabsf(argb));
@@ -287,7 +287,8 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             sinqr = sh * rcp_nr(rb);
             cosq = ch;
         }
-        // the fifteen distinct entries, surfa.f:289-320
+        // the fifteen distinct entries, surfa.f:289-320 (common factors g*rr, g1*ss and their multiples
+        // computed once)
         const float rr = rsinp * rsinq, ss = sinpr * sinqr, cc = cosp * cosq;
         const float rs1 = rsinp * cosq, rs2 = sinqr * cosp, rs3 = sinpr * cosq, rs4 = rsinq * cosp;
         const float gm = 2.0f * g - 1.0f;
@@ -295,22 +296,26 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         const float ccm = 1.0f - cc;
         const float gg1 = g * g1;
         const float rhocs = rhoc * rhoc;
-        const float suu = gs * rr + g1s * ss;
+        const float X = g * rr, Y = g1 * ss;                   // g rr, g1 ss
+        const float gX = g * X, g1Y = g1 * Y;                  // g^2 rr, g1^2 ss
+        const float Z = g * gX, W = g1 * g1Y;                  // g^3 rr, g1^3 ss
+        const float gg1c = gg1 * ccm;
+        const float suu = gX + g1Y;
         const float a11 = (2.0f * gs - gm) * cc - suu - 2.0f * gg1;
         const float a12 = -(rs1 + rs2) * irhoc;
-        const float a13 = -2.0f * (gm * ccm + g1 * ss + g * rr) * irhoc;
+        const float a13 = -2.0f * (gm * ccm + Y + X) * irhoc;
         const float a14 = (rs3 + rs4) * irhoc;
         const float a15 = (2.0f * ccm + rr + ss) * (irhoc * irhoc);
         const float a21 = rhoc * (g1s * rs3 + gs * rs4);
         const float a22 = cc;
         const float a23 = 2.0f * (g * rs4 + g1 * rs3);
         const float a24 = sinpr * rsinq;
-        const float a31 = rhoc * (gg1 * gm * ccm + g1s * g1 * ss + gs * g * rr);
+        const float a31 = rhoc * (gm * gg1c + W + Z);
         const float a32 = g1 * rs2 + g * rs1;
-        const float a33 = 1.0f + 2.0f * (2.0f * gg1 * ccm + suu);
+        const float a33 = 1.0f + 2.0f * (2.0f * gg1c + suu);
         const float a41 = -rhoc * (g1s * rs2 + gs * rs1);
         const float a42 = rsinp * sinqr;
-        const float a51 = rhocs * (2.0f * gs * g1s * ccm + gs * gs * rr + g1s * g1s * ss);
+        const float a51 = rhocs * (2.0f * gg1 * gg1c + g * Z + g1 * W);
         // compound-matrix product with its symmetries, surfa.f:326-330
         const float n1 = a11 * b1 + a12 * b2 + a13 * b3 + a14 * b4 + a15 * b5;
         const float n2 = a21 * b1 + a22 * b2 + a23 * b3 + a24 * b4 - a14 * b5;
@@ -318,7 +323,23 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         const float n4 = a41 * b1 + a42 * b2 - 2.0f * a32 * b3 + a22 * b4 - a12 * b5;
         const float n5 = a51 * b1 - a41 * b2 + 2.0f * a31 * b3 - a21 * b4 + a11 * b5;
         b1 = n1; b2 = n2; b3 = n3; b4 = n4; b5 = n5;
+    };
+    const int last = mmax - 1;                                       // the half space
+    Lyr A = load(0);
+    int m = 0;
+    while (m + 2 <= last) {
+        const Lyr Bq = load(m + 1);
+        step(A);
+        A = load(m + 2);
+        step(Bq);
+        m += 2;
     }
+    if (m < last) {
+        const Lyr Bq = load(m + 1);
+        step(A);
+        A = Bq;
+    }
+    const float n_sv = A.sv, n_ir = A.ir, n_ia2 = A.ia2, n_ib2 = A.ib2;   // layer mmax-1
     // half-space closure, surfa.f:340-354
     // (a itself is not needed: every occurrence is a^2, available as 1/ia2)
     const float sv = n_sv, irho = n_ir, ia2 = n_ia2;                 // n_* hold layer mmax-1 here
