@@ -290,6 +290,43 @@ int surfdisp_forward_batch_device_timed(void *stream, int B, int Lmax, const int
     return rc;
 }
 
+// Small calls (the one-stack drop-in fast_surf_ above all) reuse a per-thread device arena and a pinned
+// staging buffer: one host->device and one device->host copy per call instead of six, and no
+// hipMalloc/hipFree.  Kept until the thread exits.
+namespace {
+constexpr size_t ARENA_MAX = (size_t)4 << 20;         // calls needing more go through hipMalloc
+struct HostArena {
+    int dev = -1;
+    char *d = nullptr, *h = nullptr;
+    size_t dcap = 0, hcap = 0;
+    bool reserve(int device, size_t dbytes, size_t hbytes)
+    {
+        if (dev != device) { release(); dev = device; }
+        if (dbytes > dcap) {
+            if (d) (void)hipFree(d);
+            d = nullptr; dcap = 0;
+            if (hipMalloc(reinterpret_cast<void **>(&d), dbytes) != hipSuccess) return false;
+            dcap = dbytes;
+        }
+        if (hbytes > hcap) {
+            if (h) (void)hipHostFree(h);
+            h = nullptr; hcap = 0;
+            if (hipHostMalloc(reinterpret_cast<void **>(&h), hbytes, hipHostMallocDefault) != hipSuccess) return false;
+            hcap = hbytes;
+        }
+        return true;
+    }
+    void release()
+    {
+        if (d) (void)hipFree(d);
+        if (h) (void)hipHostFree(h);
+        d = h = nullptr; dcap = hcap = 0;
+    }
+    // no destructor on purpose: at thread/process exit the HIP runtime may already be gone
+};
+thread_local HostArena g_arena;
+}  // namespace
+
 int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const float *model,
                            int P, const float *per, int kind,
                            float *c, float *u, int *status)
@@ -304,25 +341,41 @@ int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const f
     if (device < 0 || device >= ndev) { set_err("bad device ordinal"); return SURFDISP_ERR_INVALID; }
     SD_HIP(hipSetDevice(device));
     const size_t nm = (size_t)B * 5 * Lmax * sizeof(float);
+    const size_t np = (size_t)P * sizeof(float);
+    const size_t ni = (size_t)B * sizeof(int);
     const size_t no = (size_t)B * P * sizeof(float);
     const size_t ws = surfdisp_workspace_bytes(B, Lmax, P);
-    char *d = nullptr;
+    // inputs [model | per | nlay] and outputs [c | u | status] are contiguous, then the workspace
     const size_t o_model = 0;
     const size_t o_per = o_model + align_up(nm);
-    const size_t o_c = o_per + align_up((size_t)P * sizeof(float));
+    const size_t o_nl = o_per + align_up(np);
+    const size_t o_c = o_nl + align_up(ni);
     const size_t o_u = o_c + align_up(no);
     const size_t o_st = o_u + align_up(no);
-    const size_t o_nl = o_st + align_up((size_t)B * sizeof(int));
-    const size_t o_ws = o_nl + align_up((size_t)B * sizeof(int));
-    SD_HIP(hipMalloc(reinterpret_cast<void **>(&d), o_ws + ws));
+    const size_t o_ws = o_st + align_up(ni);
+    const bool small = (o_ws + ws) <= ARENA_MAX;
+    char *d = nullptr, *h = nullptr;
+    if (small) {
+        if (!g_arena.reserve(device, o_ws + ws, o_ws)) { set_err("arena allocation failed"); return SURFDISP_ERR_HIP; }
+        d = g_arena.d; h = g_arena.h;
+    } else {
+        SD_HIP(hipMalloc(reinterpret_cast<void **>(&d), o_ws + ws));
+    }
     hipStream_t s = nullptr;
     int ret = SURFDISP_SUCCESS;
     do {
-        if (hipMemcpyAsync(d + o_model, model, nm, hipMemcpyHostToDevice, s) != hipSuccess ||
-            hipMemcpyAsync(d + o_per, per, (size_t)P * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess ||
-            (nlay && hipMemcpyAsync(d + o_nl, nlay, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess)) {
-            set_err("host->device copy failed"); ret = SURFDISP_ERR_HIP; break;
+        bool ok;
+        if (small) {
+            memcpy(h + o_model, model, nm);
+            memcpy(h + o_per, per, np);
+            if (nlay) memcpy(h + o_nl, nlay, ni);
+            ok = hipMemcpyAsync(d, h, o_c, hipMemcpyHostToDevice, s) == hipSuccess;
+        } else {
+            ok = hipMemcpyAsync(d + o_model, model, nm, hipMemcpyHostToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(d + o_per, per, np, hipMemcpyHostToDevice, s) == hipSuccess &&
+                 (!nlay || hipMemcpyAsync(d + o_nl, nlay, ni, hipMemcpyHostToDevice, s) == hipSuccess);
         }
+        if (!ok) { set_err("host->device copy failed"); ret = SURFDISP_ERR_HIP; break; }
         ret = surfdisp_forward_batch_device(s, B, Lmax, nlay ? reinterpret_cast<int *>(d + o_nl) : nullptr,
                                             reinterpret_cast<float *>(d + o_model), P,
                                             reinterpret_cast<float *>(d + o_per), kind,
@@ -330,15 +383,23 @@ int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const f
                                             reinterpret_cast<float *>(d + o_u),
                                             reinterpret_cast<int *>(d + o_st), d + o_ws, ws);
         if (ret) break;
-        if (hipMemcpyAsync(c, d + o_c, no, hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipMemcpyAsync(u, d + o_u, no, hipMemcpyDeviceToHost, s) != hipSuccess ||
-            (status && hipMemcpyAsync(status, d + o_st, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess)) {
-            set_err("device->host copy failed"); ret = SURFDISP_ERR_HIP; break;
+        if (small) {
+            ok = hipMemcpyAsync(h + o_c, d + o_c, o_ws - o_c, hipMemcpyDeviceToHost, s) == hipSuccess;
+        } else {
+            ok = hipMemcpyAsync(c, d + o_c, no, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipMemcpyAsync(u, d + o_u, no, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 (!status || hipMemcpyAsync(status, d + o_st, ni, hipMemcpyDeviceToHost, s) == hipSuccess);
         }
+        if (!ok) { set_err("device->host copy failed"); ret = SURFDISP_ERR_HIP; break; }
         hipError_t e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { set_err("kernel execution failed: %s", hipGetErrorString(e)); ret = SURFDISP_ERR_HIP; }
+        if (e != hipSuccess) { set_err("kernel execution failed: %s", hipGetErrorString(e)); ret = SURFDISP_ERR_HIP; break; }
+        if (small) {
+            memcpy(c, h + o_c, no);
+            memcpy(u, h + o_u, no);
+            if (status) memcpy(status, h + o_st, ni);
+        }
     } while (0);
-    (void)hipFree(d);
+    if (!small) (void)hipFree(d);
     return ret;
 }
 
