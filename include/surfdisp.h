@@ -117,6 +117,22 @@ int surfdisp_events_create(int n, void **events);
 int surfdisp_events_destroy(int n, void **events);
 int surfdisp_events_elapsed_ms(void *start, void *stop, float *ms);
 
+/* ---- (5b) forward solve + analytic sensitivity kernels.  REIGEN / LEIGEN form the
+ *          partial derivatives of the phase velocity from their energy integrals and never return
+ *          them (surfa.f:1130-1135, 1180-1183, 1204-1207; Love 561-565, 584-585); senskernel.py
+ *          re-derives them by 2L+1 perturbed solves (senskernel.py:129-158).  Here they come out of
+ *          the same group-velocity kernel launch: dcdb / dcda / dcdr [B][P][Lmax] = d c(period) /
+ *          d (Vs | Vp | rho) of input layer i in (km/s)/(km/s) resp. (km/s)/(g/cm^3), with respect
+ *          to the CALLER's layer values (the chain factors of the attenuation correction
+ *          calcul.f:122-126 and of the earth flattening flat1.f:44-62 are applied); zero for water
+ *          layers, layers below the effective half space and unsolved periods.  dcda, dcdr may be
+ *          NULL; Love has no dcda (written as zeros if given).  Same workspace as (3). */
+int surfdisp_forward_kernels_device(void *stream, int B, int Lmax, const int *nlay,
+                                    const float *model, int P, const float *per, int kind,
+                                    float *c, float *u, int *status,
+                                    float *dcdb, float *dcda, float *dcdr,
+                                    void *workspace, size_t workspace_bytes);
+
 /* ---- (6) parameters -> layer stacks on the device (the row next to the hot path, SURVEY.md 8f-2:
  *          Model1D.seisPropLayers, models.py:72-102 + layers.py:139-284) for models with a static
  *          layer structure.  params [C][N] fp64, model [C][5][L] fp32 (rows vp, vs, rho, h, 1/Qs);

@@ -24,7 +24,8 @@ EXPORTS = (
     "surfdisp_forward_batch_device", "surfdisp_forward_batch_device_timed",
     "surfdisp_forward_batch_device_events", "surfdisp_events_create", "surfdisp_events_destroy",
     "surfdisp_events_elapsed_ms", "surfdisp_params_to_model_device",
-    "surfdisp_params_to_model_thermal_device", "surfdisp_thermal_scratch_bytes", "surfdisp_set_team", "surfdisp_get_team",
+    "surfdisp_params_to_model_thermal_device", "surfdisp_thermal_scratch_bytes",
+    "surfdisp_forward_kernels_device", "surfdisp_set_team", "surfdisp_get_team",
     "surfdisp_device_count", "surfdisp_abi_version", "surfdisp_last_error",
     "surfdisp_kernel_name",
 )
@@ -85,6 +86,9 @@ def lib() -> ctypes.CDLL:
     L.surfdisp_events_elapsed_ms.argtypes = [vp, vp, fp]
     L.surfdisp_params_to_model_device.restype = ctypes.c_int
     L.surfdisp_params_to_model_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
+    L.surfdisp_forward_kernels_device.restype = ctypes.c_int
+    L.surfdisp_forward_kernels_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, vp, ctypes.c_int,
+                                                  vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t]
     L.surfdisp_thermal_scratch_bytes.restype = ctypes.c_size_t
     L.surfdisp_thermal_scratch_bytes.argtypes = [ctypes.c_int]
     L.surfdisp_params_to_model_thermal_device.restype = ctypes.c_int

@@ -139,7 +139,8 @@ size_t surfdisp_workspace_bytes(int B, int Lmax, int P)
 static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
                                const float *model, int P, const float *per, int kind,
                                float *c, float *u, int *status,
-                               void *workspace, size_t workspace_bytes, hipEvent_t *ev)
+                               void *workspace, size_t workspace_bytes, hipEvent_t *ev,
+                               float *kb = nullptr, float *ka = nullptr, float *kr = nullptr)
 {
     int rc = check_args(B, Lmax, P, kind, model, per, c, u);
     if (rc) return rc;
@@ -166,7 +167,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, status, wtol, atol};
     SD_HIP(sd::launch_phase(s, kind, G, indep, ph));
     if (ev) SD_HIP(hipEventRecord(ev[2], s));
-    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, g_dbg};
+    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, g_dbg, kb, ka, kr};
     if (!phase_only) SD_HIP(sd::launch_group(s, kind, ga));
     sd::FinishArgs fa{B, P, w.ct, phase_only ? nullptr : w.ut, c, phase_only ? nullptr : u,
                       indep ? w.nsolved : nullptr, w.nl, status};
@@ -182,6 +183,24 @@ int surfdisp_forward_batch_device(void *stream, int B, int Lmax, const int *nlay
 {
     return forward_device_impl(stream, B, Lmax, nlay, model, P, per, kind, c, u, status,
                                workspace, workspace_bytes, nullptr);
+}
+
+// Forward solve + analytic partial derivatives of the phase velocity with respect to each layer's
+// Vs, Vp, rho (what REIGEN/LEIGEN compute and discard, surfa.f:1130-1135,1204-1207 /
+// 561-565,584-585), from the energy integrals the group-velocity kernel forms anyway.
+int surfdisp_forward_kernels_device(void *stream, int B, int Lmax, const int *nlay,
+                                    const float *model, int P, const float *per, int kind,
+                                    float *c, float *u, int *status,
+                                    float *dcdb, float *dcda, float *dcdr,
+                                    void *workspace, size_t workspace_bytes)
+{
+    if (!dcdb) { set_err("surfdisp_forward_kernels_device: dcdb is NULL"); return SURFDISP_ERR_INVALID; }
+    if (kind & SURFDISP_PHASE_ONLY) {
+        set_err("surfdisp_forward_kernels_device: the partials come from the group-velocity kernel (no PHASE_ONLY)");
+        return SURFDISP_ERR_INVALID;
+    }
+    return forward_device_impl(stream, B, Lmax, nlay, model, P, per, kind, c, u, status,
+                               workspace, workspace_bytes, nullptr, dcdb, dcda, dcdr);
 }
 
 // Parameters -> layer stacks on the device for a static-structure model; the

@@ -40,6 +40,7 @@ struct GroupArgs {
     const int *nsolved;
     float *u;             // [P][B]
     double *dbg;          // nullptr, or [B][P][16] intermediate values (developer builds)
+    float *kb, *ka, *kr;  // nullptr, or [B][P][Lmax] analytic partials dc/dVs, dc/dVp, dc/drho
 };
 
 struct FinishArgs {

@@ -756,6 +756,44 @@ SD_HD __forceinline__ Drop drop_group(const float *__restrict__ mdl, size_t fs, 
     return r;
 }
 
+// Analytic partial derivatives of the phase velocity (the quantities REIGEN / LEIGEN form from their
+// energy integrals and never return: surfa.f:1130-1135, 1180-1183, 1204-1207 / 561-565, 584-585).
+// The eigenproblem is solved for the attenuation-dispersed, earth-flattened layer values; the
+// caller's derivatives are with respect to its own Vs, Vp, rho, so each layer carries the chain
+// factors of calcul.f:122-126 and flat1.f:44-62:
+//   b = b_ref (1 + qsq) f,  a = a_ref (1 + qsq 4/3 b_ref^2/a_ref^2) f,  rho = rho_ref r
+struct KernRow { float *b, *a, *r; };      // this (stack, period)'s rows [Lmax], or nullptrs
+struct Chain { float dbdb, dadb, dada, rfac; };
+SD_HD __forceinline__ Chain chain_of(const LayerRaw &r, float lnT, bool is_halfspace)
+{
+    const float qsq = r.qs * lnT / PI_REF;
+    const float qpq = qsq * 1.33333333f * (r.b_ref * r.b_ref) / (r.a_ref * r.a_ref);
+    const float vfac = is_halfspace ? r.hsf : r.dif;
+    Chain ch;
+    ch.dbdb = (1.0f + qsq) * vfac;
+    ch.dadb = 2.66666667f * qsq * (r.b_ref / r.a_ref) * vfac;
+    ch.dada = (1.0f - qpq) * vfac;
+    ch.rfac = is_halfspace ? r.hsr : r.qqq;
+    return ch;
+}
+// add one (sub)layer group's share: the six integrals of surfa.f:1110-1121 -> dL/d(lambda, mu, rho)
+// -> dc/d(b, a, rho) of the flattened layer (still to be divided by dL/dk) -> the caller's layer
+SD_HD __forceinline__ void kern_add_rayleigh(const KernRow &ko, int jl, const Chain &ch, const LayerV &v,
+                                             float xlamb, float xmu, float c, float wvno, float wvnosq,
+                                             float omegsq, double dmmr, double dmmz, double drsz,
+                                             double dzsr, double smmz, double smmr)
+{
+    const double dldl = -wvnosq * dmmr + 2.0 * wvno * drsz - smmz;
+    const double dldm = -wvnosq * (2.0 * dmmr + dmmz) - 2.0 * wvno * dzsr - (2.0 * smmz + smmr);
+    const double dldr = omegsq * (dmmr + dmmz);
+    const double db = 2.0 * v.rho * v.b * c * (dldm - 2.0 * dldl) / wvno;
+    const double da = 2.0 * v.rho * v.a * c * dldl / wvno;
+    const double dr = (c / wvno) * (dldr + xlamb * dldl / v.rho + xmu * dldm / v.rho);
+    ko.b[jl] += (float)(db * ch.dbdb + da * ch.dadb);
+    if (ko.a) ko.a[jl] += (float)(da * ch.dada);
+    if (ko.r) ko.r[jl] += (float)(dr * ch.rfac);
+}
+
 // ---- Rayleigh, surfa.f:714-1192 ---------------------------------------------------------------
 struct RCoef { float a12, a13, a21, a24, a31, a34, a42, a43, ddz; };
 
@@ -842,7 +880,8 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
                                                int n, float lnT, int ndiv, bool water, float div,
                                                const Drop dr, float wvno, float wvnosq, float omegsq,
                                                double y[4], double z[4], bool do_y,
-                                               double xnorm, double bbn, RInt &acc)
+                                               double xnorm, double bbn, RInt &acc,
+                                               const KernRow ko = KernRow{nullptr, nullptr, nullptr}, float c = 0.0f)
 {
 #pragma clang fp contract(off)   // both sweeps must see identical coefficients
     LayerRaw nraw = layer_load(mdl, fs, (size_t)dr.hs_layer * B + b);
@@ -889,7 +928,9 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
         const float dz = dsub / 4.0f;
         const float l2m = xlamb + 2.0f * xmu;
         const float ixmu = q.a34, il2m = q.a12;       // 1/mu, 1/(lambda+2mu): already formed above
-        float f_mr[5], f_mz[5], f_rz[5], f_zr[5];
+        float f_mr[5], f_mz[5], f_rz[5], f_zr[5], f_sz[5], f_sr[5];
+        const bool kern = (ko.b != nullptr);
+        double k_mr = 0.0, k_mz = 0.0, k_rz = 0.0, k_zr = 0.0, k_sz = 0.0, k_sr = 0.0;   // this layer's sums
         const double ibb = 1.0 / bbn;
         auto knot = [&](int kk) {
             // fast path: z[] is the combined, normalised solution (xnorm*y + z)/bb itself;
@@ -905,11 +946,13 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
             const float duzdz = (atz + wvno * xlamb * aur) * il2m;
             f_mr[kk] = aur * aur; f_mz[kk] = auz * auz;
             f_rz[kk] = aur * duzdz; f_zr[kk] = auz * durdz;
+            if (kern) { f_sz[kk] = duzdz * duzdz; f_sr[kk] = durdz * durdz; }
         };
         for (int s = 0; s < nreg; ++s) {
             // bottom knot: the top knot of the sublayer below when it belongs to the same layer
             if (s == 0) knot(4);
-            else { f_mr[4] = f_mr[0]; f_mz[4] = f_mz[0]; f_rz[4] = f_rz[0]; f_zr[4] = f_zr[0]; }
+            else { f_mr[4] = f_mr[0]; f_mz[4] = f_mz[0]; f_rz[4] = f_rz[0]; f_zr[4] = f_zr[0];
+                   f_sz[4] = f_sz[0]; f_sr[4] = f_sr[0]; }
 #pragma unroll
             for (int kk = 3; kk >= 0; --kk) {
                 if (two_vec) prop_apply(P, y);
@@ -920,16 +963,24 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
 #define SD_BOOLE(v) (hq * (7.0f * (v[0] + v[4]) + 32.0f * (v[1] + v[3]) + 12.0f * v[2]))
             const double dmmr = SD_BOOLE(f_mr), dmmz = SD_BOOLE(f_mz);
             const double drsz = SD_BOOLE(f_rz), dzsr = SD_BOOLE(f_zr);
+            if (kern) {
+                k_mr += dmmr; k_mz += dmmz; k_rz += drsz; k_zr += dzsr;
+                k_sz += SD_BOOLE(f_sz); k_sr += SD_BOOLE(f_sr);
+            }
 #undef SD_BOOLE
             acc.i0 += v.rho * (dmmr + dmmz);                        // surfa.f:1126-1128
             acc.i1 += l2m * dmmr + xmu * dmmz;
             acc.i2 += xmu * dzsr - xlamb * drsz;
         }
+        if (kern)
+            kern_add_rayleigh(ko, jl, chain_of(raw, lnT, jl == n - 1), v, xlamb, xmu, c, wvno, wvnosq, omegsq,
+                              k_mr, k_mz, k_rz, k_zr, k_sz, k_sr);
     }
 }
 
 SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
-                                float T, float c, float ratio, double *dbg = nullptr)
+                                float T, float c, float ratio, double *dbg = nullptr,
+                                const KernRow ko = KernRow{nullptr, nullptr, nullptr})
 {
 #pragma clang fp contract(off)
     const float lnT = logf(1.0f / T);
@@ -977,6 +1028,16 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
             acc.i1 = xl1 * fac2;
             acc.i2 = xl1 * fac3;
             tzz = -top.rho * omegsq * sinra_over / cosra;
+            if (ko.b) {
+                // the water layer's own partials (the reference skips liquid layers, surfa.f:1088): in a
+                // fluid the dilatation is tau_zz/lambda, so int theta^2 dz = k^2 (c/a)^4 int ur^2 dz
+                const LayerRaw wraw = layer_load(mdl, fs, (size_t)b);
+                const Chain ch = chain_of(wraw, lnT, false);
+                const double dldl = -(double)wvnosq * (ra * ra) * (ra * ra) * fac2;
+                const double dldr = (double)omegsq * (fac1 + fac2);
+                if (ko.a) ko.a[0] += (float)(2.0 * top.rho * top.a * c * dldl / wvno * ch.dada);
+                if (ko.r) ko.r[0] += (float)((c / wvno) * (dldr + (double)top.a * top.a * dldl) * ch.rfac);
+            }
         }
     }
     // half-space start vectors, surfa.f:913-926, 986-989
@@ -1040,7 +1101,7 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
         for (int i = 0; i < 4; ++i) { z[i] = (xnorm * y0[i] + z0[i]) / bbn; y[i] = 0.0; }
         aur = (float)z[0]; auz = (float)z[1];
         rayleigh_sweep<2>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
-                          y, z, false, xnorm, bbn, acc);
+                          y, z, false, xnorm, bbn, acc, ko, c);
     } else {
         // Robust path (thick structure / short period: the solutions grow by up to ~1e27 and the
         // rounding noise excited on the way up is far larger than the answer).  The reference stays
@@ -1054,7 +1115,7 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
         aur = (float)((xnorm * y0[0] + z0[0]) / bbn);
         auz = (float)((xnorm * y0[1] + z0[1]) / bbn);
         rayleigh_sweep<2>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
-                          y, z, true, xnorm, bbn, acc);
+                          y, z, true, xnorm, bbn, acc, ko, c);
     }
     if (wet && !any_solid) { aur = ratio; auz = 1.0f; }              // label 77777, surfa.f:1140-1144
     {   // label 7002, surfa.f:1145-1186
@@ -1074,15 +1135,30 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
         acc.i0 += hsv.rho * (dmmr + dmmz);
         acc.i1 += (xlamb + 2.0f * xmu) * dmmr + xmu * dmmz;
         acc.i2 += xmu * dzsr - xlamb * drsz;
+        if (ko.b) {                                                   // surfa.f:1163-1164, 1178-1183
+            const double smmz = ra * a3 * a3 / 2.0f + 2.0f * ra * rb * a3 * a4 / (ra + rb) + rb * a4 * a4 / 2.0f;
+            const double smmr = ra * a1 * a1 / 2.0f + 2.0f * ra * rb * a1 * a2 / (ra + rb) + rb * a2 * a2 / 2.0f;
+            const LayerRaw hraw = layer_load(mdl, fs, (size_t)dr.hs_layer * B + b);
+            kern_add_rayleigh(ko, dr.hs_layer, chain_of(hraw, lnT, dr.hs_layer == n - 1), hsv, xlamb, xmu, c,
+                              wvno, wvnosq, omegsq, dmmr, dmmz, drsz, dzsr, smmz, smmr);
+        }
     }
     if (dbg) { dbg[10] = acc.i0; dbg[11] = acc.i1; dbg[15] = acc.i2; }
     const float s0 = (float)acc.i0, s1 = (float)acc.i1, s2 = (float)acc.i2;
+    if (ko.b) {                                                       // surfa.f:1203-1207
+        const float idldk = 1.0f / (-2.0f * (wvno * s1 + s2));
+        for (int i = 0; i <= dr.hs_layer; ++i) {
+            ko.b[i] *= idldk;
+            if (ko.a) ko.a[i] *= idldk;
+            if (ko.r) ko.r[i] *= idldk;
+        }
+    }
     return (wvno * s1 + s2) / (omega * s0);                           // surfa.f:1186
 }
 
 // ---- Love, surfa.f:374-606 (all fp32, as the reference) --------------------------------------
 SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
-                            float T, float c)
+                            float T, float c, const KernRow ko = KernRow{nullptr, nullptr, nullptr})
 {
     const float lnT = logf(1.0f / T);
     int ndiv = 5;
@@ -1095,9 +1171,21 @@ SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, i
     const Drop dr = drop_group<1>(mdl, fs, B, b, n, lnT, c, T, ndiv, water, div);
     const float wvno = 6.2831853f / (c * T);
     const LayerV hsv = layer_at(mdl, fs, (size_t)dr.hs_layer * B + b, lnT, dr.hs_layer == n - 1);
+    const bool kern = (ko.b != nullptr);
+    const float wvnosq = wvno * wvno;
+    const float omega = 6.2831853f / T, omegsq = omega * omega;
+    // one layer's share of dc/db, dc/drho (surfa.f:561-565), still to be divided by dL/dk
+    auto kern_add = [&](int jl, const LayerRaw &raw, const LayerV &v, float dm, float sm) {
+        const Chain ch = chain_of(raw, lnT, jl == n - 1);
+        const float dldm = -(wvnosq * dm + sm);
+        const float dldr = omegsq * dm;
+        ko.b[jl] += 2.0f * v.rho * v.b * c * dldm / wvno * ch.dbdb;
+        if (ko.r) ko.r[jl] += (c / wvno) * (dldr + v.b * v.b * dldm) * ch.rfac;
+    };
     float ut0 = 1.0f;
     for (int attempt = 0; attempt < 16; ++attempt) {
         float ut = ut0;
+        if (kern) for (int i = 0; i <= dr.hs_layer; ++i) { ko.b[i] = 0.0f; if (ko.r) ko.r[i] = 0.0f; }
         const float covb = c / hsv.b;
         const float hh = hsv.rho * hsv.b * hsv.b;
         const float rbh = wvno * sqrtf(fabsf(covb * covb - 1.0f));
@@ -1107,6 +1195,9 @@ SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, i
         float sumi1 = hh * dm0;
         bool overflow = false;
         LayerRaw nraw = layer_load(mdl, fs, (size_t)dr.hs_layer * B + b);
+        // the half space itself: u = ut0 exp(-rb z), so int u^2 = ut0^2/(2 rb), int (du/dz)^2 = ut0^2 rb/2
+        // (the reference leaves its half-space entry at zero, surfa.f:578-579; the share is real)
+        if (kern && rbh > 0.0f) kern_add(dr.hs_layer, nraw, hsv, dm0, 0.5f * rbh);
         for (int jl = dr.hs_layer; jl >= 0 && !overflow; --jl) {
             const LayerRaw raw = nraw;
             if (jl > 0) nraw = layer_load(mdl, fs, (size_t)(jl - 1) * B + b);
@@ -1141,24 +1232,36 @@ SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, i
                     yk[kk] = sn / rb; zk[kk] = -rb * sn; ck[kk] = cs;
                 }
             }
+            float k_dm = 0.0f, k_sm = 0.0f;
             for (int s = 0; s < nreg; ++s) {
                 if (fabsf(ut) > 1.0e10f) { overflow = true; break; } // surfa.f:519-522
-                float dmm[5];
+                float dmm[5], smm[5];
                 dmm[0] = ut * ut;
+                smm[0] = (tq / h) * (tq / h);
                 float eut = ut, ett = tq;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     eut = ck[kk] * ut - yk[kk] * tq / h;
                     ett = -h * zk[kk] * ut + ck[kk] * tq;
                     dmm[kk + 1] = eut * eut;
+                    smm[kk + 1] = (ett * ett) / (h * h);
                 }
                 ut = eut; tq = ett;
                 const float dm = (dz / 22.5f) * (7.0f * (dmm[0] + dmm[4]) + 32.0f * (dmm[1] + dmm[3]) + 12.0f * dmm[2]);
                 sumi0 = sumi0 + v.rho * dm;
                 sumi1 = sumi1 + h * dm;
+                if (kern) {
+                    k_dm += dm;
+                    k_sm += (dz / 22.5f) * (7.0f * (smm[0] + smm[4]) + 32.0f * (smm[1] + smm[3]) + 12.0f * smm[2]);
+                }
             }
+            if (kern && !overflow) kern_add(jl, raw, v, k_dm, k_sm);
         }
         if (overflow) { ut0 = ut0 / 1.0e5f; continue; }
+        if (kern) {                                                   // surfa.f:581-585
+            const float idldk = 1.0f / (-2.0f * wvno * sumi1);
+            for (int i = 0; i <= dr.hs_layer; ++i) { ko.b[i] *= idldk; if (ko.r) ko.r[i] *= idldk; }
+        }
         sumi0 = sumi0 / (ut * ut);
         sumi1 = sumi1 / (ut * ut);
         return sumi1 / (c * sumi0);                                   // surfa.f:606
@@ -1175,14 +1278,26 @@ __global__ __launch_bounds__(256) void surfdisp_group_kernel(GroupArgs A)
     const int b = (int)(idx % B), k = (int)(idx / B);       // a wavefront = 64 stacks, one period
     const size_t o = idx;                                   // period-major [P][B]: coalesced
     const int n = A.nl[b];
+    KernRow ko{nullptr, nullptr, nullptr};
+    if (A.kb) {                                             // caller's [B][P][Lmax] rows, zero-filled
+        const size_t ro = ((size_t)b * P + k) * A.Lmax;
+        ko.b = A.kb + ro;
+        ko.a = (KIND == 2 && A.ka) ? A.ka + ro : nullptr;
+        ko.r = A.kr ? A.kr + ro : nullptr;
+        for (int i = 0; i < A.Lmax; ++i) {
+            ko.b[i] = 0.0f;
+            if (A.ka) A.ka[ro + i] = 0.0f;
+            if (ko.r) ko.r[i] = 0.0f;
+        }
+    }
     if (n < 2 || k >= A.nsolved[b]) { A.u[o] = 0.0f; return; }
     const size_t fs = (size_t)A.Lmax * B;
     const float T = A.per[k];
     const float c = A.c[o];
     float ugr;
     if (KIND == 2) ugr = group_rayleigh(A.mdl, fs, B, b, n, T, c, A.ratio[(size_t)k * B + b],
-                                        A.dbg ? A.dbg + 16 * o : nullptr);
-    else           ugr = group_love(A.mdl, fs, B, b, n, T, c);
+                                        A.dbg ? A.dbg + 16 * o : nullptr, ko);
+    else           ugr = group_love(A.mdl, fs, B, b, n, T, c, ko);
     A.u[o] = ugr;
 }
 

@@ -130,6 +130,35 @@ class BatchPlan:
         return self.c, self.u, self.status
 
 
+    def run_kernels(self, model, periods, kind=2, nlay=None, want_vp=True, want_rho=True):
+        """Forward solve + analytic partial derivatives of the phase velocity
+        (``surfdisp_forward_kernels_device``): returns (c, u, status, dcdb, dcda, dcdr) with the
+        partials float32 [B, P, L] = d c(period) / d (Vs | Vp | rho) of input layer i (``None`` where
+        not requested; Love has no dcda).  Same launch as ``run`` plus per-layer sums in the
+        group-velocity kernel - what ``SensKernelPert`` obtains from 2L+1 perturbed solves."""
+        torch = self.torch
+        for t, shape in ((model, (self.B, 5, self.L)), (periods, (self.P,))):
+            if (t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shape
+                    or t.device != self.device):
+                raise ValueError(f"expected contiguous float32 {shape} on {self.device}")
+        if nlay is not None and (nlay.dtype != torch.int32 or nlay.numel() != self.B
+                                 or nlay.device != self.device):
+            raise ValueError("nlay must be int32 [B] on the same device")
+        mk = lambda: torch.empty((self.B, self.P, self.L), dtype=torch.float32, device=self.device)
+        dcdb = mk()
+        dcda = mk() if (want_vp and (int(kind) & 3) == _lib.KIND_RAYLEIGH) else None
+        dcdr = mk() if want_rho else None
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().surfdisp_forward_kernels_device(
+                ctypes.c_void_p(stream), self.B, self.L, ptr(nlay), ptr(model), self.P, ptr(periods), int(kind),
+                ptr(self.c), ptr(self.u), ptr(self.status), ptr(dcdb), ptr(dcda), ptr(dcdr),
+                ptr(self.workspace), self.ws_bytes)
+        _lib.check(rc)
+        return self.c, self.u, self.status, dcdb, dcda, dcdr
+
+
 class EventRing:
     """n x 4 HIP events owned by the caller, recorded by ``BatchPlan.run(..., events=ring.slot(i))``
     on the launch stream; ``kernel_ms()`` (after the caller synchronised) returns the

@@ -125,3 +125,24 @@ def sens_kernel_pert_batch(model, periods, wtype="R", nlay=None, lo=0.999, hi=1.
             out[name][a:a + n] = torch.where(bad | (h <= 0), torch.full_like(k, float("nan")), k)
         out["c0"][a:a + n], out["u0"][a:a + n], out["status"][a:a + n] = c[:, 0], u[:, 0], st[:, 0]
     return out
+
+
+def analytic_kernels(model, periods, wtype="R", nlay=None, want_vp=True, want_rho=True):
+    """Sensitivity kernels of a whole batch from ONE forward solve (``surfdisp_forward_kernels_device``):
+    the partial derivatives REIGEN / LEIGEN form from their energy integrals and never return
+    (surfa.f:1130-1135, 1204-1207; 561-565, 584-585), with the chain factors of the attenuation
+    correction and the earth flattening applied so that they refer to the caller's layer values.
+
+    model: torch float32 [M, 5, L] (vp, vs, rho, h, 1/Qs) on a HIP device; periods float32 [P].
+    Returns dict(dcdb, dcda, dcdr: float32 [M, P, L] = d c / d (Vs | Vp | rho) per layer (dcda only for
+    Rayleigh); c0, u0 [M, P]; status [M]; phv = dcdb * Vs / 100 / h, the reference's ``SensKernelPert``
+    units ((v(1.001 Vs) - v(0.999 Vs)) / 0.2 / H, senskernel.py:150))."""
+    import torch
+    kind = {"R": 2, "L": 1}[wtype]
+    M, _, L = model.shape
+    plan = _forward.BatchPlan(M, L, periods.numel(), device=model.device)
+    c, u, st, kb, ka, kr = plan.run_kernels(model, periods, kind=kind, nlay=nlay, want_vp=want_vp, want_rho=want_rho)
+    h = model[:, 3, :][:, None, :]
+    vs = model[:, 1, :][:, None, :]
+    phv = torch.where(h > 0, kb * vs / 100.0 / torch.where(h > 0, h, torch.ones_like(h)), torch.zeros_like(kb))
+    return dict(dcdb=kb, dcda=ka, dcdr=kr, c0=c, u0=u, status=st, phv=phv)

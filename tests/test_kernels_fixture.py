@@ -74,3 +74,92 @@ def test_hip_finite_difference_kernels_vs_reference_fixture(w, kind):
     ref = layer_means(w, H)
     o = np.isfinite(ref)
     assert np.abs(k[o] - ref[o]).max() < 0.05 * np.abs(ref[o]).max()
+
+
+def _fd_oracle(m, per, kind, row, eps=0.01):
+    """Central differences of the CPU oracle, 1 % perturbations of one column (1 Vs, 0 Vp, 2 rho)."""
+    from oracle import cport
+    L = m.shape[2]
+    big = np.repeat(m, 2 * L, axis=0)
+    for i in range(L):
+        big[i, row, i] *= (1 - eps); big[L + i, row, i] *= (1 + eps)
+    co, _, so = cport.forward_batch(big, per, kind, nthreads=8)
+    assert (so == 0).all()
+    fd = ((co[L:].astype(np.float64) - co[:L]) / (2 * eps * np.where(m[0, row] != 0, m[0, row], 1.0)[:, None])).T
+    fd[:, m[0, row] == 0] = 0
+    return fd
+
+
+def _kernel_cases():
+    from pysurfinv_amd import synth
+    cases = {"synth_L12": synth.synth_models(2, 12, seed=3)[:1], "eus_L68": EUS["model"].astype(np.float32)}
+    wm = synth.synth_models(1, 9, seed=5)
+    wm[0, 1, 0] = 0.0; wm[0, 0, 0] = 1.5; wm[0, 2, 0] = 1.03; wm[0, 3, 0] = 3.0
+    cases["water_L9"] = wm
+    return cases
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["synth_L12", "eus_L68", "water_L9"])
+@pytest.mark.parametrize("w,kind", [("R", 2), ("L", 1)])
+def test_analytic_kernels_match_oracle_finite_differences(name, w, kind):
+    """surfdisp_forward_kernels_device: dc/dVs, dc/dVp, dc/drho of every layer from the energy integrals
+    of ONE solve against central finite differences of the CPU oracle (2L solves per column).
+    Measured 3e-4 .. 2.5e-3 of each period's largest entry = the noise of fp32 differences; bar 6e-3."""
+    import torch
+    from pysurfinv_amd import senskernel
+    m = _kernel_cases()[name]
+    per = np.asarray(PERIODS, np.float32)
+    out = senskernel.analytic_kernels(torch.from_numpy(m).cuda(), torch.from_numpy(per).cuda(), wtype=w)
+    assert int(out["status"][0]) == 0
+    for row, key in ((1, "dcdb"), (0, "dcda"), (2, "dcdr")):
+        if out[key] is None:
+            assert w == "L" and key == "dcda"
+            continue
+        an = out[key][0].cpu().numpy().astype(np.float64)
+        fd = _fd_oracle(m, per, kind, row)
+        scale = np.abs(fd).max(axis=1, keepdims=True)
+        assert (np.abs(an - fd) / scale).max() < 6e-3, (name, w, key)
+        assert np.abs(an.sum(1) - fd.sum(1)).max() < 8e-3 * np.abs(fd.sum(1)).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w", ["R", "L"])
+def test_analytic_kernels_vs_reference_fixture(w):
+    """The same analytic (dc/c)/(db/b) per km as the reference's senskernel-1.0 known-answer files."""
+    import torch
+    from pysurfinv_amd import senskernel
+    H = eus_columns()[0]
+    m = EUS["model"].astype(np.float32)
+    per = torch.as_tensor(np.asarray(PERIODS, np.float32)).cuda()
+    out = senskernel.analytic_kernels(torch.from_numpy(m).cuda(), per, wtype=w)
+    c0 = out["c0"][0].cpu().numpy().astype(np.float64)
+    k = out["dcdb"][0].cpu().numpy().astype(np.float64) * m[0, 1][None, :] / H[None, :] / c0[:, None]
+    ref = layer_means(w, H)
+    for ip in range(len(PERIODS)):
+        o = np.isfinite(ref[ip])
+        assert np.abs(k[ip][o] - ref[ip][o]).max() < 0.05 * np.abs(ref[ip][o]).max(), (w, PERIODS[ip])
+
+
+@pytest.mark.gpu
+def test_analytic_kernels_batch_rows_and_failures():
+    """Rows of a ragged batch equal the one-stack results; unsolved periods and bad stacks give zeros."""
+    import torch
+    from pysurfinv_amd import forward, synth
+    m = synth.synth_models(6, 10, seed=2)
+    m[3, 1, 4] = 0.4                                        # a strong low-velocity layer
+    m[5, 0, 2] = -1.0                                       # bad stack
+    nlay = np.array([10, 7, 10, 10, 5, 10], np.int32)
+    per = synth.default_periods(20)
+    plan = forward.BatchPlan(6, 10, 20)
+    c, u, st, kb, ka, kr = plan.run_kernels(torch.from_numpy(m).cuda(), torch.from_numpy(per).cuda(), kind=2,
+                                            nlay=torch.from_numpy(nlay).cuda())
+    c, st, kb = c.cpu().numpy(), st.cpu().numpy(), kb.cpu().numpy()
+    assert st[5] == 4 and not kb[5].any()
+    assert not kb[c == 0].any()                             # unsolved (stack, period): zero rows
+    for i in (0, 1, 4):
+        n = int(nlay[i])
+        p1 = forward.BatchPlan(1, n, 20)
+        c1, _, s1, kb1, _, _ = p1.run_kernels(torch.from_numpy(np.ascontiguousarray(m[i:i + 1, :, :n])).cuda(),
+                                              torch.from_numpy(per).cuda(), kind=2)
+        assert np.array_equal(kb[i, :, :n], kb1[0].cpu().numpy()) and not kb[i, :, n:].any()
