@@ -58,6 +58,10 @@ def main():
     print(json.dumps({"stage": "joint Rayleigh+Love c+U", "stacks": B, "layers": L, "ms": dt * 1e3,
                       "stacks_per_s": B / dt, "solves_per_s": 2 * B / dt, "solved_R": okR, "solved_L": okL}), flush=True)
     for w in ("R", "L"):
+        dt, k = timed(lambda: senskernel.analytic_kernels(model, per, wtype=w, nlay=nlay), 3)
+        print(json.dumps({"stage": f"analytic dc/dVs, dc/dVp, dc/drho kernels of every layer (one solve), {w}", "stacks": B,
+                          "layers": L, "ms": dt * 1e3, "kernel_sets_per_s": B / dt}), flush=True)
+    for w in ("R", "L"):
         dt, k = timed(lambda: senskernel.sens_kernel_pert_batch(model[:MS], per, wtype=w, nlay=None if nlay is None else nlay[:MS]), 2)
         nan = float(torch.isnan(k["phv"]).float().mean())
         print(json.dumps({"stage": f"finite-difference Vs sensitivity kernels, {w}", "stacks": MS, "layers": L,
