@@ -53,7 +53,11 @@ enum {
     SURFDISP_OK         = 0,   /* all P periods solved */
     SURFDISP_PARTIAL    = 1,   /* bracketing failed at period k>1: c,U of periods k..P are 0 (calcul.f:203,218-219) */
     SURFDISP_NOROOT     = 2,   /* bracketing failed at the first period: everything 0 (calcul.f:203-212) */
-    SURFDISP_BADMODEL   = 4    /* nlay < 2, nlay > Lmax, or non-finite input: everything 0 */
+    SURFDISP_BADMODEL   = 4,   /* nlay < 2, nlay > Lmax, or non-finite input: everything 0 */
+    SURFDISP_NUMERIC    = 8    /* the secular function left the fp32 range (NaN) during the root search (very
+                                * thick layers at short periods).  The reference's NEVILL then exhausts its 50
+                                * cycles and the call returns nothing (surfa.f:17-27, calcul.f:172-189):
+                                * everything 0, also the periods already solved */
 };
 
 /* return codes */

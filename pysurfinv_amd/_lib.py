@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsurfdisp_hip.so")
 
 SUCCESS, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_WORKSPACE = 0, -1, -2, -3, -4
-OK, PARTIAL, NOROOT, BADMODEL = 0, 1, 2, 4
+OK, PARTIAL, NOROOT, BADMODEL, NUMERIC = 0, 1, 2, 4, 8
 KIND_LOVE, KIND_RAYLEIGH = 1, 2
 PHASE_ONLY = 0x10
 INDEPENDENT = 0x20

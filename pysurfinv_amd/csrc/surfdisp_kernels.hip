@@ -376,33 +376,43 @@ __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, con
     float h = W_R(mh) * bm * bm;
     float rb = sqrt_hw(fabsf(fmaf(csq, W_IB2(mh), -1.0f)));          // sqrt|c^2/b^2 - 1|
     float ut = 1.0f, tt = h * rb;
-    const int m0 = (mh - 1 > 0) ? mh - 1 : 0;
-    float n_b = W_B(m0), n_d = W_D(m0), n_ib2 = W_IB2(m0), n_r = W_R(m0);
-    for (int m = mh - 1; m >= 0; --m) {
-        bm = n_b;
-        const float d = n_d, ib2 = n_ib2, rho = n_r;
-        const int mp = (m > 0) ? m - 1 : 0;                // next layer up, in flight during this one
-        n_b = W_B(mp); n_d = W_D(mp); n_ib2 = W_IB2(mp); n_r = W_R(mp);
-        if (bm == 0.0f) continue;                          // water, surfa.f:152
+    // layer m-1's four LDS values are in flight while layer m is computed; unrolled by two over
+    // alternating register sets
+    struct Lyr { float b, d, ib2, r; };
+    auto load = [&](int m) -> Lyr { const int q = m > 0 ? m : 0; return {W_B(q), W_D(q), W_IB2(q), W_R(q)}; };
+    auto step = [&](const Lyr &y) {
+        bm = y.b;
+        const float d = y.d, ib2 = y.ib2, rho = y.r;
+        if (bm == 0.0f) return;                            // water, surfa.f:152
         rb = sqrt_hw(fabsf(fmaf(csq, ib2, -1.0f)));
         h = rho * bm * bm;
         const float ih = rcp_nr(h);
         const float q = -wvno * d * rb;
-        float y, z, cosq;
-        if (rb < 0.1e-20f || c == bm) { y = -wvno * d; z = 0.0f; cosq = 1.0f; }
+        float yv, z, cosq;
+        if (rb < 0.1e-20f || c == bm) { yv = -wvno * d; z = 0.0f; cosq = 1.0f; }
         else if (c < bm) {
             float sh, ch; sinhcosh_sp(q, &sh, &ch);
-            y = sh * rcp_nr(rb);
-            z = -rb * rb * y;
+            yv = sh * rcp_nr(rb);
+            z = -rb * rb * yv;
             cosq = ch;
         } else {
             float sn, cs; sincos_cw(q, &sn, &cs);
-            y = sn * rcp_nr(rb); z = rb * sn; cosq = cs;
+            yv = sn * rcp_nr(rb); z = rb * sn; cosq = cs;
         }
-        const float eut = cosq * ut - y * tt * ih;
+        const float eut = cosq * ut - yv * tt * ih;
         const float ett = h * z * ut + cosq * tt;
         ut = eut; tt = ett;
+    };
+    int m = mh - 1;
+    Lyr A = load(m);
+    while (m >= 1) {
+        const Lyr Bq = load(m - 1);
+        step(A);
+        A = load(m - 2);
+        step(Bq);
+        m -= 2;
     }
+    if (m == 0) step(A);
     return -tt;
 }
 
@@ -570,7 +580,8 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         const int pmm = (j == 0) ? p0mm : smm;
         const bool searching = ((st == ST_SCAN) || (st == ST_REFINE)) && !ell_lane;
         const bool has_prev = !((st == ST_SCAN) && first && (js == 0));
-        const bool cross = has_prev && (signbit(val) != signbit(pd));
+        auto negnan = [](float x) { return signbit(x) && !(x != x); };   // a NaN compares as positive, see below
+        const bool cross = has_prev && (negnan(val) != negnan(pd));
         bool guard = false;
         if (st == ST_SCAN && has_prev && !cross)               // calcul.f:165-166
             guard = (cj < 0.8f * b1top) || !(cj < W_B(mmj - 1) + 0.3f);
@@ -593,11 +604,24 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         const float pl_c = __shfl(cj, pl), pl_d = __shfl(val, pl);
 
         bool solved = false, failed = false;
+        // A secular function that left the fp32 range (NaN: products of e^{k d} terms beyond 3e38 in
+        // very thick layers at short periods).  The reference's scan compares SIGN(1., del): the NaNs
+        // its arithmetic produces carry the sign bit (x86 default NaN) and both secular functions
+        // return the NEGATED recursion result (surfa.f:179,357), so a NaN passes as a positive value
+        // (negnan above); once a NaN is an end of the bracket it poisons NEVILL's interpolation,
+        // the 50-cycle limit trips and the whole call returns nothing (surfa.f:17-27 ->
+        // calcul.f:172-189 -> 9999).  Same here: a bracket with a NaN end, or a NaN refine point,
+        // fails the stack.
+        const bool nan_bracket = (st == ST_SCAN) && (fl >= 0) && e_cross && ((e_d != e_d) || (e_pd != e_pd));
+        const bool nan_refine = (st == ST_REFINE) && ((__ballot(eval && (val != val)) & tmask) != 0ull);
+        const bool fatal = nan_bracket || nan_refine;
         if (OVERLAP && ell_pend && st == ST_SCAN) {
             if (j == 0) A.ratio[(size_t)ell_k * B + b] = 0.5f * v1 / v0;   // surfa.f:363
             ell_pend = false;
         }
-        if (st == ST_SCAN) {
+        if (fatal) {
+            nsolved = 0; k = 0; status = SURFDISP_NUMERIC; st = ST_DONE; ell_pend = false;
+        } else if (st == ST_SCAN) {
             ++passes;
             if (fl >= 0 && e_cross) {                          // bracket found -> refine
                 p0c = e_pc; p0d = e_pd; cb = e_c; db = e_d; mm_frozen = e_mm;
@@ -701,7 +725,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         // period index is reduced over the stack's teams; the finish kernel applies it
         if (team_valid && j == 0 && n >= 2 && status != SURFDISP_OK) {
             A.c[(size_t)k_own * B + b] = 0.0f;
-            atomicMin(&A.nsolved[b], k_own);
+            atomicMin(&A.nsolved[b], status == SURFDISP_NUMERIC ? 0 : k_own);
         }
         return;
     }

@@ -11,7 +11,8 @@ from oracle import cport
 rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "0")))
 T_END = time.time() + float(os.environ.get("SOAK_SECONDS", "120"))
 worst = dict(c=0.0, u=0.0)
-nstack = ncase = npat = 0
+T_LAST = time.time()
+nstack = ncase = npat = novf = 0
 bad_cases = []
 while time.time() < T_END:
     L = int(rng.integers(2, 48)); B = int(rng.integers(64, 2048)); kind = int(rng.integers(1, 3))
@@ -39,6 +40,7 @@ while time.time() < T_END:
     ec = np.abs(c[ok] / co[ok] - 1) if ok.any() else np.zeros(1)
     eu = np.abs(u[ok] / uo[ok] - 1) if ok.any() else np.zeros(1)
     nstack += B; ncase += 1; npat += int((~rows).sum())
+    novf += int((~rows & ((st == 8) | (so == 3))).sum())     # fp32-overflow regime: either side gave up
     q = np.quantile(eu, 0.999) if eu.size > 1000 else eu.max()
     if ec.max() > 2e-5 or q > 1e-4 or (~rows).mean() > 0.02 or not np.isfinite(c).all() or not np.isfinite(u).all():
         bad_cases.append((L, B, kind, noise, mono, P, team, float(ec.max()), float(eu.max()), float(q), int((~rows).sum())))
@@ -53,8 +55,13 @@ while time.time() < T_END:
                                 nlay=(nlay[idx] if nlay is not None else np.full(len(idx), L, np.int32)),
                                 c=c[idx], u=u[idx], co=co[idx], uo=uo[idx], st=st[idx], so=so[idx])
     worst["c"] = max(worst["c"], float(ec.max())); worst["u"] = max(worst["u"], float(q))
+    if time.time() - T_LAST > 45:                           # progress line (the GPU box kills silent runs)
+        T_LAST = time.time()
+        print(f"  ... {ncase} cases, {nstack} stacks, pattern mismatches {npat}, flagged {len(bad_cases)}", flush=True)
 _lib.lib().surfdisp_set_team(0)
 print(f"soak: {ncase} cases, {nstack} stacks, zero-pattern mismatches {npat} stacks "
-      f"({npat / max(nstack, 1):.2e}), worst c {worst['c']:.2e}, worst U(99.9%) {worst['u']:.2e}")
-for b in bad_cases[:20]:
+      f"({npat / max(nstack, 1):.2e}; {novf} of them where the secular function overflowed fp32: SURFDISP_NUMERIC "
+      f"or the oracle's NEVILL failure), worst c {worst['c']:.2e}, worst U(99.9%) {worst['u']:.2e}")
+bad_cases.sort(key=lambda t: (-t[10], -t[7]))
+for b in bad_cases[:40]:
     print("  flagged: L=%d B=%d kind=%d noise=%.2f mono=%s P=%d team=%d  c %.1e  Umax %.1e  U99.9 %.1e  pattern %d" % b)

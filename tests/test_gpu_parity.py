@@ -375,3 +375,24 @@ def test_independent_mode_failure_cascade_and_water(hip, ref_cases):
     d = ref_cases["water_L9_L"]
     c, u, st = hip.forward_batch(d["model"], d["periods"], 1, independent=True)
     assert np.isfinite(c).all() and c.shape == d["c"].shape
+
+
+def test_fp32_overflow_fails_the_stack_like_the_reference(hip):
+    """Two 200 km layers at T = 5 s: the secular function overflows fp32 (NaN).  The reference's NEVILL
+    then exhausts its 50 cycles and the whole call returns nothing - also the periods that could be
+    solved (calcul.f:172-189).  The HIP path reports SURFDISP_NUMERIC and zeros; neighbours in the
+    same batch are unaffected."""
+    from oracle import cport
+    from pysurfinv_amd import synth, _lib
+    m = synth.synth_models(64, 2, seed=2, noise=0.05, monotone=False, total_thickness=400.0)
+    ok = synth.synth_models(64, 2, seed=3, noise=0.1, monotone=True, total_thickness=60.0)
+    model = np.concatenate([m, ok]).astype(np.float32)
+    per = np.linspace(5, 100, 24).astype(np.float32)
+    for team in (0, 1, 4, 64):
+        assert _lib.lib().surfdisp_set_team(team) == 0
+        c, u, st = hip.forward_batch(model, per, 2)
+        co, uo, so = cport.forward_batch(model, per, 2, nthreads=8)
+        assert (so[:64] == 3).all() and not co[:64].any()            # oracle: NEVILL failure, no output
+        assert (st[:64] == _lib.NUMERIC).all() and not c[:64].any() and not u[:64].any()
+        assert (st[64:] == 0).all() and relerr(c[64:], co[64:]) < 2e-5 and relerr(u[64:], uo[64:]) < 1e-4
+    _lib.lib().surfdisp_set_team(0)
