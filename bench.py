@@ -113,7 +113,9 @@ def main():
     per = torch.from_numpy(per_np).to(dev)
     # Two batches in flight on two HIP streams: the root-search kernel's wavefronts finish at
     # different times, and a second independent batch fills the idle SIMD slots (measured +15 %).
-    # Same work per step; the one-batch-in-flight rate is reported beside it.
+    # Same work per step; the one-batch-in-flight rate is reported beside it.  With a second batch in
+    # flight the launches carry SURFDISP_PIPELINED (lanes per stack chosen for both batches: 2 instead
+    # of 4 here, +6 % measured); results are identical for every team size (tests/test_gpu_parity.py).
     NFLIGHT = int(os.environ.get("BENCH_IN_FLIGHT", "2"))
     plans = [forward.BatchPlan(B_PER_GPU, NLAY, NPER, device=dev) for _ in range(NFLIGHT)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NFLIGHT)]
@@ -130,7 +132,8 @@ def main():
     def steps(n, nflight, record=False):
         for i in range(n):
             with torch.cuda.stream(streams[i % nflight]):
-                plans[i % nflight].run(model, per, kind=KIND, events=ring.slot(i) if record else None)
+                plans[i % nflight].run(model, per, kind=KIND, events=ring.slot(i) if record else None,
+                                       pipelined=nflight > 1)
 
     steps(max(args.warmup, NFLIGHT), NFLIGHT)
     barrier()
@@ -193,7 +196,9 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 65536 MCMC-perturbed 10-layer stacks per GPU, "
                                    "Rayleigh phase+group velocity at 20 periods",
                        "stacks_per_gpu": B_PER_GPU, "layers": NLAY, "periods": NPER,
-                       "wave": "Rayleigh c+U", "batches_in_flight": NFLIGHT, "team_lanes": int(_lib.lib().surfdisp_get_team(B_PER_GPU, NLAY)),
+                       "wave": "Rayleigh c+U", "batches_in_flight": NFLIGHT,
+                       "team_lanes": int(_lib.lib().surfdisp_get_team(B_PER_GPU * (2 if NFLIGHT > 1 else 1), NLAY)),
+                       "team_lanes_one_batch_in_flight": int(_lib.lib().surfdisp_get_team(B_PER_GPU, NLAY)),
                        "sharding": f"independent stacks, {world} rank(s), no data-path collective"},
             "solved_fraction": float(ok.item()) / (world * B_PER_GPU),
             "value_one_batch_in_flight": world * B_PER_GPU * args.steps / elapsed_one,

@@ -44,6 +44,10 @@ extern "C" {
                                      * monotone stacks but NOT on rough ones (low-velocity zones), where
                                      * the reference's sequential start rule picks roots and failures
                                      * (SURVEY.md section 4 defects 2, 9).  Caller opts in. */
+#define SURFDISP_PIPELINED     0x40 /* OR into `kind`: a launch hint, results are unchanged.  The caller keeps a
+                                     * second batch of this size in flight on another stream, so the lanes per
+                                     * stack are chosen for twice the stacks (fewer lanes per stack waste fewer
+                                     * trial velocities; with one batch alone they would leave SIMDs idle) */
 #define SURFDISP_PHASE_ONLY    0x10 /* OR into `kind` of the batched entries: phase velocities only
                                      * (what Point.misfit consumes, point.py:18); u is not written
                                      * and may be NULL */

@@ -16,6 +16,7 @@ OK, PARTIAL, NOROOT, BADMODEL, NUMERIC = 0, 1, 2, 4, 8
 KIND_LOVE, KIND_RAYLEIGH = 1, 2
 PHASE_ONLY = 0x10
 INDEPENDENT = 0x20
+PIPELINED = 0x40
 NPER_MAX, NLAY_MAX = 200, 200
 
 # every symbol include/surfdisp.h declares

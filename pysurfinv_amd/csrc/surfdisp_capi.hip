@@ -78,7 +78,7 @@ int pick_team(int B, int Lmax)
 int check_args(int B, int Lmax, int P, int kind, const void *model, const void *per,
                const void *c, const void *u)
 {
-    const int wave = kind & ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT);
+    const int wave = kind & ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED);
     if (B < 1 || Lmax < 2 || Lmax > SURFDISP_NLAY_MAX || P < 1 || P > SURFDISP_NPER_MAX ||
         (wave != SURFDISP_KIND_LOVE && wave != SURFDISP_KIND_RAYLEIGH) || !model || !per || !c ||
         (!u && !(kind & SURFDISP_PHASE_ONLY))) {
@@ -151,10 +151,12 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool phase_only = (kind & SURFDISP_PHASE_ONLY) != 0;
     const bool indep = (kind & SURFDISP_INDEPENDENT) != 0;
-    kind &= ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT);
+    const bool pipelined = (kind & SURFDISP_PIPELINED) != 0;
+    kind &= ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED);
     const Carve w = carve(workspace, B, Lmax, P);
-    // independent mode has B*P root searches in flight: size the teams for that many
-    const long units = indep ? (long)B * P : (long)B;
+    // independent mode has B*P root searches in flight: size the teams for that many; a caller that
+    // keeps a second batch in flight (SURFDISP_PIPELINED) has twice the stacks on the chip
+    const long units = (indep ? (long)B * P : (long)B) * (pipelined ? 2 : 1);
     const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax);
 
     sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl, P, indep ? w.nsolved : nullptr};

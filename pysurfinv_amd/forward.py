@@ -96,12 +96,17 @@ class BatchPlan:
         measured with HIP events on the launch stream (surfdisp_forward_batch_device_timed)."""
         return self.run(model, periods, kind=kind, nlay=nlay, _timed=True, independent=independent)
 
-    def run(self, model, periods, kind=2, nlay=None, _timed=False, independent=False, events=None):
+    def run(self, model, periods, kind=2, nlay=None, _timed=False, independent=False, events=None,
+            pipelined=False):
         """Launch the kernels on torch's current stream (no allocation, no sync).  ``events``: an
-        ``EventRing`` slot (4 HIP events recorded on the launch stream around the kernels)."""
+        ``EventRing`` slot (4 HIP events recorded on the launch stream around the kernels).
+        ``pipelined``: the caller keeps a second batch in flight on another stream
+        (``SURFDISP_PIPELINED``: a launch hint, same results)."""
         torch = self.torch
         if independent:
             kind = int(kind) | _lib.INDEPENDENT
+        if pipelined:
+            kind = int(kind) | _lib.PIPELINED
         for t, shape in ((model, (self.B, 5, self.L)), (periods, (self.P,))):
             if (t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shape
                     or t.device != self.device):

@@ -17,7 +17,9 @@ echo "trace rc=$?"
 export BENCH_IN_FLIGHT=1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_one" -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/trace_one.log" 2>&1
 echo "trace_one rc=$?"
-unset BENCH_IN_FLIGHT
+# the counter passes keep one batch in flight too: the counters then describe the launch configuration
+# whose kernel durations bench.py brackets with HIP events (with a second batch in flight the launches
+# carry SURFDISP_PIPELINED and use two-lane teams)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
 echo "pmc fetch rc=$?"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > "$OUT/pmc_write.log" 2>&1
@@ -27,3 +29,4 @@ echo "pmc sq rc=$?"
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_TRANS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq2" -- $BENCH > "$OUT/pmc_sq2.log" 2>&1
 echo "pmc sq2 rc=$?"
 find "$OUT" -name "*.csv" | head -40
+unset BENCH_IN_FLIGHT
