@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 B_PER_GPU = 65536
 NLAY = 10
 NPER = 20
-KIND = 2                      # Rayleigh
+KIND = 2 | int(os.environ.get("BENCH_KIND_FLAGS", "0"), 0)   # Rayleigh (c + U); development: extra kind flags
 ALG_BYTES_PER_SOLVE = 20 * NLAY + 8 * NPER    # 5 fp32 arrays in, (c, U) out = 360 B
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 

@@ -899,7 +899,7 @@ SD_HD __forceinline__ void prop_apply(const RProp &P, double v[4])
 // MODE 2: energy integrals.  two_vec = false: z[] is the combined solution itself (fast path);
 //         two_vec = true: y[] and z[] are stepped separately and combined at every knot with the
 //         fitted xnorm / bb, exactly like the reference's stored knots (surfa.f:1092-1095).
-template <int MODE>
+template <int MODE, bool KERN = false>
 SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t fs, int B, int b,
                                                int n, float lnT, int ndiv, bool water, float div,
                                                const Drop dr, float wvno, float wvnosq, float omegsq,
@@ -953,7 +953,7 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
         const float l2m = xlamb + 2.0f * xmu;
         const float ixmu = q.a34, il2m = q.a12;       // 1/mu, 1/(lambda+2mu): already formed above
         float f_mr[5], f_mz[5], f_rz[5], f_zr[5], f_sz[5], f_sr[5];
-        const bool kern = (ko.b != nullptr);
+        constexpr bool kern = KERN;
         double k_mr = 0.0, k_mz = 0.0, k_rz = 0.0, k_zr = 0.0, k_sz = 0.0, k_sr = 0.0;   // this layer's sums
         const double ibb = 1.0 / bbn;
         auto knot = [&](int kk) {
@@ -1002,6 +1002,7 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
     }
 }
 
+template <bool KERN = false>
 SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
                                 float T, float c, float ratio, double *dbg = nullptr,
                                 const KernRow ko = KernRow{nullptr, nullptr, nullptr})
@@ -1052,7 +1053,7 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
             acc.i1 = xl1 * fac2;
             acc.i2 = xl1 * fac3;
             tzz = -top.rho * omegsq * sinra_over / cosra;
-            if (ko.b) {
+            if (KERN) {
                 // the water layer's own partials (the reference skips liquid layers, surfa.f:1088): in a
                 // fluid the dilatation is tau_zz/lambda, so int theta^2 dz = k^2 (c/a)^4 int ur^2 dz
                 const LayerRaw wraw = layer_load(mdl, fs, (size_t)b);
@@ -1124,8 +1125,8 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
         // rounding noise the fastest-growing solution picks up on the way (<= 1e7 * 1e-16).
         for (int i = 0; i < 4; ++i) { z[i] = (xnorm * y0[i] + z0[i]) / bbn; y[i] = 0.0; }
         aur = (float)z[0]; auz = (float)z[1];
-        rayleigh_sweep<2>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
-                          y, z, false, xnorm, bbn, acc, ko, c);
+        rayleigh_sweep<2, KERN>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
+                                y, z, false, xnorm, bbn, acc, ko, c);
     } else {
         // Robust path (thick structure / short period: the solutions grow by up to ~1e27 and the
         // rounding noise excited on the way up is far larger than the answer).  The reference stays
@@ -1138,8 +1139,8 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
         for (int i = 0; i < 4; ++i) { y[i] = y0[i]; z[i] = z0[i]; }
         aur = (float)((xnorm * y0[0] + z0[0]) / bbn);
         auz = (float)((xnorm * y0[1] + z0[1]) / bbn);
-        rayleigh_sweep<2>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
-                          y, z, true, xnorm, bbn, acc, ko, c);
+        rayleigh_sweep<2, KERN>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
+                                y, z, true, xnorm, bbn, acc, ko, c);
     }
     if (wet && !any_solid) { aur = ratio; auz = 1.0f; }              // label 77777, surfa.f:1140-1144
     {   // label 7002, surfa.f:1145-1186
@@ -1159,7 +1160,7 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
         acc.i0 += hsv.rho * (dmmr + dmmz);
         acc.i1 += (xlamb + 2.0f * xmu) * dmmr + xmu * dmmz;
         acc.i2 += xmu * dzsr - xlamb * drsz;
-        if (ko.b) {                                                   // surfa.f:1163-1164, 1178-1183
+        if (KERN) {                                                   // surfa.f:1163-1164, 1178-1183
             const double smmz = ra * a3 * a3 / 2.0f + 2.0f * ra * rb * a3 * a4 / (ra + rb) + rb * a4 * a4 / 2.0f;
             const double smmr = ra * a1 * a1 / 2.0f + 2.0f * ra * rb * a1 * a2 / (ra + rb) + rb * a2 * a2 / 2.0f;
             const LayerRaw hraw = layer_load(mdl, fs, (size_t)dr.hs_layer * B + b);
@@ -1169,7 +1170,7 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
     }
     if (dbg) { dbg[10] = acc.i0; dbg[11] = acc.i1; dbg[15] = acc.i2; }
     const float s0 = (float)acc.i0, s1 = (float)acc.i1, s2 = (float)acc.i2;
-    if (ko.b) {                                                       // surfa.f:1203-1207
+    if (KERN) {                                                       // surfa.f:1203-1207
         const float idldk = 1.0f / (-2.0f * (wvno * s1 + s2));
         for (int i = 0; i <= dr.hs_layer; ++i) {
             ko.b[i] *= idldk;
@@ -1181,6 +1182,7 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
 }
 
 // ---- Love, surfa.f:374-606 (all fp32, as the reference) --------------------------------------
+template <bool KERN = false>
 SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
                             float T, float c, const KernRow ko = KernRow{nullptr, nullptr, nullptr})
 {
@@ -1195,7 +1197,7 @@ SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, i
     const Drop dr = drop_group<1>(mdl, fs, B, b, n, lnT, c, T, ndiv, water, div);
     const float wvno = 6.2831853f / (c * T);
     const LayerV hsv = layer_at(mdl, fs, (size_t)dr.hs_layer * B + b, lnT, dr.hs_layer == n - 1);
-    const bool kern = (ko.b != nullptr);
+    constexpr bool kern = KERN;
     const float wvnosq = wvno * wvno;
     const float omega = 6.2831853f / T, omegsq = omega * omega;
     // one layer's share of dc/db, dc/drho (surfa.f:561-565), still to be divided by dL/dk
@@ -1261,14 +1263,14 @@ SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, i
                 if (fabsf(ut) > 1.0e10f) { overflow = true; break; } // surfa.f:519-522
                 float dmm[5], smm[5];
                 dmm[0] = ut * ut;
-                smm[0] = (tq / h) * (tq / h);
+                if (kern) smm[0] = (tq / h) * (tq / h);
                 float eut = ut, ett = tq;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     eut = ck[kk] * ut - yk[kk] * tq / h;
                     ett = -h * zk[kk] * ut + ck[kk] * tq;
                     dmm[kk + 1] = eut * eut;
-                    smm[kk + 1] = (ett * ett) / (h * h);
+                    if (kern) smm[kk + 1] = (ett * ett) / (h * h);
                 }
                 ut = eut; tq = ett;
                 const float dm = (dz / 22.5f) * (7.0f * (dmm[0] + dmm[4]) + 32.0f * (dmm[1] + dmm[3]) + 12.0f * dmm[2]);
@@ -1293,8 +1295,14 @@ SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, i
     return 0.0f;
 }
 
-template <int KIND>
-__global__ __launch_bounds__(256) void surfdisp_group_kernel(GroupArgs A)
+// KERN: also write the analytic partials (A.kb/ka/kr).  The plain variant is held to 168 VGPRs (three
+// wavefronts per SIMD instead of two).
+template <int KIND, bool KERN>
+#ifndef SD_GROUP_WAVES
+#define SD_GROUP_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KERN ? 1 : SD_GROUP_WAVES, 8)))
+void surfdisp_group_kernel(GroupArgs A)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int B = A.B, P = A.P;
@@ -1303,7 +1311,7 @@ __global__ __launch_bounds__(256) void surfdisp_group_kernel(GroupArgs A)
     const size_t o = idx;                                   // period-major [P][B]: coalesced
     const int n = A.nl[b];
     KernRow ko{nullptr, nullptr, nullptr};
-    if (A.kb) {                                             // caller's [B][P][Lmax] rows, zero-filled
+    if (KERN) {                                             // caller's [B][P][Lmax] rows, zero-filled
         const size_t ro = ((size_t)b * P + k) * A.Lmax;
         ko.b = A.kb + ro;
         ko.a = (KIND == 2 && A.ka) ? A.ka + ro : nullptr;
@@ -1319,9 +1327,9 @@ __global__ __launch_bounds__(256) void surfdisp_group_kernel(GroupArgs A)
     const float T = A.per[k];
     const float c = A.c[o];
     float ugr;
-    if (KIND == 2) ugr = group_rayleigh(A.mdl, fs, B, b, n, T, c, A.ratio[(size_t)k * B + b],
-                                        A.dbg ? A.dbg + 16 * o : nullptr, ko);
-    else           ugr = group_love(A.mdl, fs, B, b, n, T, c, ko);
+    if (KIND == 2) ugr = group_rayleigh<KERN>(A.mdl, fs, B, b, n, T, c, A.ratio[(size_t)k * B + b],
+                                              A.dbg ? A.dbg + 16 * o : nullptr, ko);
+    else           ugr = group_love<KERN>(A.mdl, fs, B, b, n, T, c, ko);
     A.u[o] = ugr;
 }
 
@@ -1429,8 +1437,11 @@ hipError_t launch_group(hipStream_t s, int kind, const GroupArgs &a)
 {
     const size_t total = (size_t)a.B * a.P;
     const int grid = (int)((total + 255) / 256);
-    if (kind == 2) hipLaunchKernelGGL(surfdisp_group_kernel<2>, dim3(grid), dim3(256), 0, s, a);
-    else           hipLaunchKernelGGL(surfdisp_group_kernel<1>, dim3(grid), dim3(256), 0, s, a);
+    const bool kern = a.kb != nullptr;
+    if (kind == 2 && kern)  hipLaunchKernelGGL((surfdisp_group_kernel<2, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (kind == 2)     hipLaunchKernelGGL((surfdisp_group_kernel<2, false>), dim3(grid), dim3(256), 0, s, a);
+    else if (kern)          hipLaunchKernelGGL((surfdisp_group_kernel<1, true>), dim3(grid), dim3(256), 0, s, a);
+    else                    hipLaunchKernelGGL((surfdisp_group_kernel<1, false>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
