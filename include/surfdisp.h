@@ -48,6 +48,15 @@ extern "C" {
                                      * second batch of this size in flight on another stream, so the lanes per
                                      * stack are chosen for twice the stacks (fewer lanes per stack waste fewer
                                      * trial velocities; with one batch alone they would leave SIMDs idle) */
+#define SURFDISP_FASTSCAN      0x80 /* OR into `kind`: certified coarse-to-fine scan.  The reference evaluates the
+                                     * secular function at every 0.01 km/s from 0.9 c(k-1) up to the first sign
+                                     * change (calcul.f:143-166).  With this flag the search steps over four
+                                     * grid points at a time where three consecutive coarse values (same layer
+                                     * dropping, same sign, second difference below twice the smaller end
+                                     * value) rule out a pair of roots in between, and rescans point by point
+                                     * everywhere else: same grid, same bracket, ~3 x fewer evaluations.  The
+                                     * certificate is a smoothness argument, not a proof: the caller opts in
+                                     * (tests/test_gpu_parity.py and scripts/soak.py compare both modes). */
 #define SURFDISP_PHASE_ONLY    0x10 /* OR into `kind` of the batched entries: phase velocities only
                                      * (what Point.misfit consumes, point.py:18); u is not written
                                      * and may be NULL */

@@ -78,7 +78,7 @@ int pick_team(int B, int Lmax)
 int check_args(int B, int Lmax, int P, int kind, const void *model, const void *per,
                const void *c, const void *u)
 {
-    const int wave = kind & ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED);
+    const int wave = kind & ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED | SURFDISP_FASTSCAN);
     if (B < 1 || Lmax < 2 || Lmax > SURFDISP_NLAY_MAX || P < 1 || P > SURFDISP_NPER_MAX ||
         (wave != SURFDISP_KIND_LOVE && wave != SURFDISP_KIND_RAYLEIGH) || !model || !per || !c ||
         (!u && !(kind & SURFDISP_PHASE_ONLY))) {
@@ -152,7 +152,8 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     const bool phase_only = (kind & SURFDISP_PHASE_ONLY) != 0;
     const bool indep = (kind & SURFDISP_INDEPENDENT) != 0;
     const bool pipelined = (kind & SURFDISP_PIPELINED) != 0;
-    kind &= ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED);
+    const bool fastscan = (kind & SURFDISP_FASTSCAN) != 0;
+    kind &= ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED | SURFDISP_FASTSCAN);
     const Carve w = carve(workspace, B, Lmax, P);
     // independent mode has B*P root searches in flight: size the teams for that many; a caller that
     // keeps a second batch in flight (SURFDISP_PIPELINED) has twice the stacks on the chip
@@ -166,7 +167,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     float wtol = 1.2e-3f, atol = 1.0e-6f;
     if (const char *e = getenv("SURFDISP_WTOL")) wtol = (float)atof(e);
     if (const char *e = getenv("SURFDISP_ATOL")) atol = (float)atof(e);
-    sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, status, wtol, atol};
+    sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, status, wtol, atol, fastscan ? 1 : 0};
     SD_HIP(sd::launch_phase(s, kind, G, indep, ph));
     if (ev) SD_HIP(hipEventRecord(ev[2], s));
     sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, g_dbg, kb, ka, kr};

@@ -28,6 +28,7 @@ struct PhaseArgs {
     int *status;          // [B] or nullptr
     float wtol;           // bracket width below which the root may be read off by interpolation
     float atol;           // ... provided secant and 3-point estimates agree to this (km/s)
+    int fast;             // SURFDISP_FASTSCAN: certified coarse-to-fine scan
 };
 
 struct GroupArgs {

@@ -447,7 +447,8 @@ enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3 };
 //   period, on a freshly built full stack.  P times more teams, P times shorter dependency chain:
 //   the mode for small batches; equal to the faithful mode to ~1e-6 on well-behaved (monotone)
 //   stacks, NOT on rough ones (defects 2 and 9) - the caller opts in.
-template <int KIND, int G, bool INDEP>
+// FAST = true: SURFDISP_FASTSCAN (instantiated for teams of 2, 4 and 8 lanes only).
+template <int KIND, int G, bool INDEP, bool FAST = false>
 __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
 {
     extern __shared__ float w_lds[];
@@ -485,6 +486,14 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
     bool p0ok = false;                 // p0d was computed with mm_frozen (usable for interpolation)
     bool first = true;
     int status = SURFDISP_OK;
+    // SURFDISP_FASTSCAN (teams of 2..8 lanes): after the first pass of a period the scan advances
+    // FSTRIDE grid points per lane; an interval between two coarse points is skipped only if it is
+    // certified free of sign changes (see below), otherwise its fine points are scanned as usual
+    constexpr int FSTRIDE = 4;
+    constexpr bool fastok = FAST && (G >= 2) && (G <= 8);
+    bool coarse = false;               // this pass scans on the coarse grid
+    int fine_left = 1;                 // fine points still to scan before going (back) to coarse
+    float q0d = 0.0f; int q0mm = 0; bool q0ok = false;   // the coarse point before p0 (for lane 0)
     // pending ellipticity of the previous period (OVERLAP): evaluated by lanes 0-1 of the first
     // scan pass of the next period instead of costing a pass of its own
     bool ell_pend = false;
@@ -537,10 +546,13 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
             cj = ell_c; mmj = ell_mm; start = 2 + j; wl = wq2; Tl = ell_T;
         } else if (st == ST_SCAN) {
             // exact fp32 grid of the reference: c2 = c1 + dc repeatedly (calcul.f:157,161)
-            const int nadd = first ? js : js + 1;
+            const int nadd = (fastok && coarse) ? FSTRIDE * (js + 1) : (first ? js : js + 1);
             cj = p0c;
+            if (fastok) { for (int i = 0; i < nadd; ++i) cj = cj + DC; }
+            else {
 #pragma unroll
-            for (int i = 0; i < G; ++i) if (i < nadd) cj = cj + DC;
+                for (int i = 0; i < G; ++i) if (i < nadd) cj = cj + DC;
+            }
             mmj = drop_layers(wq, Lcap, S, n, cj, T);          // idrop=0 before every scan trial
         } else if (st == ST_REFINE) {
             const float w = cb - p0c;
@@ -585,7 +597,30 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         bool guard = false;
         if (st == ST_SCAN && has_prev && !cross)               // calcul.f:165-166
             guard = (cj < 0.8f * b1top) || !(cj < W_B(mmj - 1) + 0.3f);
-        const bool ev = searching && (cross || guard);
+        // coarse pass: the interval (previous coarse point, this one) may be skipped only if the
+        // secular function has the same sign at both ends, was evaluated with the same effective
+        // half space at three consecutive coarse points around it, and bends so little over them
+        // (second difference < 2 x the smaller end value; a dip to zero inside would need ~8 x) that
+        // no pair of roots can hide in it.  Anything else is rescanned point by point.
+        bool uncert = false;
+        if (fastok) {
+        const int ln1 = (lane + 1) & 63, lm2 = (lane + 62) & 63;
+        const float nx_d = __shfl(val, ln1), sp_d = __shfl(val, lm2);
+        const int nx_mm = __shfl(mmj, ln1), sp_mm = __shfl(mmj, lm2);
+        if (coarse && st == ST_SCAN) {
+            const bool has_next = (j < G - 1);
+            const bool has_pp = (j >= 1) || q0ok;
+            const float pp_d = (j >= 2) ? sp_d : ((j == 1) ? p0d : q0d);
+            const int pp_mm = (j >= 2) ? sp_mm : ((j == 1) ? p0mm : q0mm);
+            const float lim = 2.0f * fminf(fabsf(pd), fabsf(val));
+            const bool okf = !has_next || ((pmm == mmj) && (mmj == nx_mm) && fin(nx_d) &&
+                                           (fabsf(pd - 2.0f * val + nx_d) < lim));
+            const bool okb = !has_pp || ((pp_mm == pmm) && (pmm == mmj) && fin(pp_d) &&
+                                         (fabsf(pp_d - 2.0f * pd + val) < lim));
+            uncert = !((has_next || has_pp) && okf && okb && fin(pd) && fin(val));
+        }
+        }
+        const bool ev = searching && (cross || guard || uncert);
         const unsigned long long em = __ballot(ev) & tmask;
         const int fl = em ? (__ffsll((long long)em) - 1) : -1;
         const int src = (fl < 0) ? tbase : fl;
@@ -602,6 +637,8 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         const float e_nc = __shfl(cj, nxt), e_nd = __shfl(val, nxt);
         const int pl = (G > 1) ? lastl - 1 : lastl;            // lane before the last one
         const float pl_c = __shfl(cj, pl), pl_d = __shfl(val, pl);
+        const int pl_mm = __shfl(mmj, pl);
+        const bool had_ell = OVERLAP && ell_pend && (st == ST_SCAN);
 
         bool solved = false, failed = false;
         // A secular function that left the fp32 range (NaN: products of e^{k d} terms beyond 3e38 in
@@ -612,7 +649,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         // the 50-cycle limit trips and the whole call returns nothing (surfa.f:17-27 ->
         // calcul.f:172-189 -> 9999).  Same here: a bracket with a NaN end, or a NaN refine point,
         // fails the stack.
-        const bool nan_bracket = (st == ST_SCAN) && (fl >= 0) && e_cross && ((e_d != e_d) || (e_pd != e_pd));
+        const bool nan_bracket = (st == ST_SCAN) && !(fastok && coarse) && (fl >= 0) && e_cross && ((e_d != e_d) || (e_pd != e_pd));
         const bool nan_refine = (st == ST_REFINE) && ((__ballot(eval && (val != val)) & tmask) != 0ull);
         const bool fatal = nan_bracket || nan_refine;
         if (OVERLAP && ell_pend && st == ST_SCAN) {
@@ -621,6 +658,15 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         }
         if (fatal) {
             nsolved = 0; k = 0; status = SURFDISP_NUMERIC; st = ST_DONE; ell_pend = false;
+        } else if (fastok && st == ST_SCAN && coarse) {
+            ++passes;
+            if (fl >= 0) {                                     // rescan this interval point by point
+                p0c = e_pc; p0d = e_pd; p0mm = e_pmm;
+                coarse = false; fine_left = FSTRIDE; q0ok = false;
+            } else {
+                q0d = pl_d; q0mm = pl_mm; q0ok = true;
+                p0c = l_c; p0d = l_d; p0mm = l_mm;
+            }
         } else if (st == ST_SCAN) {
             ++passes;
             if (fl >= 0 && e_cross) {                          // bracket found -> refine
@@ -636,6 +682,10 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
             } else {
                 p0c = l_c; p0d = l_d; p0mm = l_mm; first = false;
                 if (passes > 100000) failed = true;            // cannot happen: c grows by dc/pass
+                if (fastok) {
+                    fine_left -= had_ell ? G - 2 : G;
+                    if (fine_left <= 0) { coarse = true; q0ok = false; }
+                }
             }
         } else if (st == ST_REFINE) {
             // new bracket + one more known point next to it (for the final 3-point step)
@@ -712,6 +762,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
                 b1top = W_B(0);
                 p0c = 0.90f * croot;                           // calcul.f:143
                 p0d = 0.0f; p0mm = 0; p0ok = false; first = true; passes = 0;
+                coarse = false; fine_left = 1; q0ok = false;
                 st = ST_SCAN;
             }
         }
@@ -1373,12 +1424,12 @@ __global__ __launch_bounds__(256) void surfdisp_finish_kernel(FinishArgs A)
 // ======================================================================================= launch
 namespace {
 
-template <int KIND, int G, bool INDEP>
+template <int KIND, int G, bool INDEP, bool FAST = false>
 hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 {
     constexpr int S = 256 / G;
     const size_t lds = sd::phase_lds_bytes(a.Lmax, G);
-    auto kern = sd::surfdisp_phase_kernel<KIND, G, INDEP>;
+    auto kern = sd::surfdisp_phase_kernel<KIND, G, INDEP, FAST>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1391,6 +1442,14 @@ hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 template <int KIND, bool INDEP>
 hipError_t launch_phase_k(hipStream_t s, const sd::PhaseArgs &a, int G)
 {
+    if (a.fast) {                                  // SURFDISP_FASTSCAN: teams of 2..8 lanes; others ignore it
+        switch (G) {
+            case 2:  return launch_phase_g<KIND, 2, INDEP, true>(s, a);
+            case 4:  return launch_phase_g<KIND, 4, INDEP, true>(s, a);
+            case 8:  return launch_phase_g<KIND, 8, INDEP, true>(s, a);
+            default: break;
+        }
+    }
     switch (G) {
         case 1:  return launch_phase_g<KIND, 1, INDEP>(s, a);
         case 2:  return launch_phase_g<KIND, 2, INDEP>(s, a);
