@@ -20,8 +20,13 @@ SIMDS = 1024
 
 
 def short(name):
+    """Kernel family of a trace/counter row; the opt-in instantiations (SURFDISP_FASTSCAN root search,
+    group kernel with analytic partials: last template argument true) are kept out of the summary."""
     for k in KERNELS:
         if k in name:
+            targs = name.split("<")[-1].split(">")[0].replace(" ", "")
+            if k in ("surfdisp_phase_kernel", "surfdisp_group_kernel") and targs.endswith("true"):
+                return None
             return k
     return None
 
