@@ -55,8 +55,10 @@ extern "C" {
                                      * dropping, same sign, second difference below twice the smaller end
                                      * value) rule out a pair of roots in between, and rescans point by point
                                      * everywhere else: same grid, same bracket, ~3 x fewer evaluations.  The
-                                     * certificate is a smoothness argument, not a proof: the caller opts in
-                                     * (tests/test_gpu_parity.py and scripts/soak.py compare both modes). */
+                                     * certificate is a smoothness argument, not a proof (two modes closer than
+                                     * 0.04 km/s - Love overtones on layers many wavelengths thick, channel waves
+                                     * of strong low-velocity zones - are invisible to it): the caller opts in
+                                     * (tests/test_gpu_parity.py, scripts/soak_fastscan.py compare both modes). */
 #define SURFDISP_PHASE_ONLY    0x10 /* OR into `kind` of the batched entries: phase velocities only
                                      * (what Point.misfit consumes, point.py:18); u is not written
                                      * and may be NULL */

@@ -617,7 +617,10 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
                                            (fabsf(pd - 2.0f * val + nx_d) < lim));
             const bool okb = !has_pp || ((pp_mm == pmm) && (pmm == mmj) && fin(pp_d) &&
                                          (fabsf(pp_d - 2.0f * pd + val) < lim));
-            uncert = !((has_next || has_pp) && okf && okb && fin(pd) && fin(val));
+            // the secular function is analytic in c except at the half-space velocity (its closure is
+            // linear in sqrt|c^2/b^2 - 1|): within two coarse steps of that branch point nothing is skipped
+            const bool near_hs = !(cj < W_B(mmj - 1) - 2.0f * (float)FSTRIDE * DC);
+            uncert = near_hs || !((has_next || has_pp) && okf && okb && fin(pd) && fin(val));
         }
         }
         const bool ev = searching && (cross || guard || uncert);

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""GPU-only soak: SURFDISP_FASTSCAN against the faithful scan, bit for bit, on random stacks.
+SOAK_MONO=1: monotone stacks only (Vs, Vp non-decreasing with depth)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from pysurfinv_amd import _lib, forward, synth
+
+L = _lib.lib()
+rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "0")))
+T_END = time.time() + float(os.environ.get("SOAK_SECONDS", "120"))
+MONO = os.environ.get("SOAK_MONO", "1") == "1"
+T_LAST = time.time()
+nst = nval = ndif = npat = ncase = 0
+worst = []
+while time.time() < T_END:
+    Ln = int(rng.integers(2, 48)); B = 4096; kind = int(rng.integers(1, 3))
+    noise = float(rng.choice([0.02, 0.05, 0.1, 0.2])); tt = float(rng.choice([30., 60., 120., 200., 400.]))
+    mono = True if MONO else bool(rng.random() < 0.5)
+    m = synth.synth_models(B, Ln, seed=int(rng.integers(1 << 30)), noise=noise, monotone=mono, total_thickness=tt)
+    if rng.random() < 0.2 and Ln >= 4:
+        m[:, 1, 0] = 0.0; m[:, 0, 0] = 1.475; m[:, 2, 0] = 1.027; m[:, 4, 0] = 1e-4; m[:, 3, 0] = rng.uniform(0.3, 4.0, B)
+    P = int(rng.integers(1, 40))
+    per = np.sort(rng.uniform(3.0, 150.0, P)).astype(np.float32)
+    team = int(rng.choice([2, 4, 8])); L.surfdisp_set_team(team)
+    md = torch.from_numpy(m).cuda(); pd = torch.from_numpy(per).cuda()
+    plan = forward.BatchPlan(B, Ln, P)
+    c0, u0, s0 = plan.run(md, pd, kind=kind | 0x10); c0 = c0.clone(); s0 = s0.clone()
+    c1, u1, s1 = plan.run(md, pd, kind=kind | 0x10, fastscan=True)
+    d = (c0 != c1)
+    nd = int(d.sum()); ndif += nd; nval += c0.numel(); nst += B; ncase += 1
+    npat += int(((c0 > 0) != (c1 > 0)).any(dim=1).sum())
+    if nd:
+        worst.append((nd, Ln, kind, noise, tt, P, team, float((c0 - c1).abs().max())))
+    if time.time() - T_LAST > 45:
+        T_LAST = time.time()
+        print(f"  ... {ncase} cases, {nst} stacks, {nval} phase velocities, {ndif} differ, {npat} stacks with another zero pattern", flush=True)
+L.surfdisp_set_team(0)
+print(f"fastscan soak (monotone only: {MONO}): {ncase} cases, {nst} stacks, {nval} phase velocities; {ndif} differ ({ndif / max(nval, 1):.2e}); "
+      f"{npat} stacks with a different zero pattern")
+for w in sorted(worst, reverse=True)[:15]:
+    print("   differ %d: L=%d kind=%d noise=%.2f thick=%.0f P=%d team=%d max|dc|=%.2e" % w)
