@@ -912,14 +912,27 @@ SD_HD __forceinline__ RProp make_prop(const RCoef &q)
     const double k4 = t6 * w1 * wh * wh;
     const M2x2 m1 = {(double)q.a31, (double)q.a34, (double)q.a21, (double)q.a24};
     const M2x2 m2 = {(double)q.a13, (double)q.a12, (double)q.a43, (double)q.a42};
-    const M2x2 n1 = mm(m1, m2), n2 = mm(m2, m1);
-    const M2x2 n1s = mm(n1, n1), n2s = mm(n2, n2);
-    const M2x2 n1m1 = mm(n1, m1), n2m2 = mm(n2, m2);
+    // one block of P at a time: the products of a block die before the next one starts (register
+    // pressure: this kernel sits at the 168-VGPR boundary of three wavefronts per SIMD)
     RProp P;
-    P.p11 = {1.0 + (k2 * n1.a + k4 * n1s.a), k2 * n1.b + k4 * n1s.b, k2 * n1.c + k4 * n1s.c, 1.0 + (k2 * n1.d + k4 * n1s.d)};
-    P.p22 = {1.0 + (k2 * n2.a + k4 * n2s.a), k2 * n2.b + k4 * n2s.b, k2 * n2.c + k4 * n2s.c, 1.0 + (k2 * n2.d + k4 * n2s.d)};
-    P.p12 = {k1 * m1.a + k3 * n1m1.a, k1 * m1.b + k3 * n1m1.b, k1 * m1.c + k3 * n1m1.c, k1 * m1.d + k3 * n1m1.d};
-    P.p21 = {k1 * m2.a + k3 * n2m2.a, k1 * m2.b + k3 * n2m2.b, k1 * m2.c + k3 * n2m2.c, k1 * m2.d + k3 * n2m2.d};
+    {
+        const M2x2 n1 = mm(m1, m2);
+        {
+            const M2x2 n1s = mm(n1, n1);
+            P.p11 = {1.0 + (k2 * n1.a + k4 * n1s.a), k2 * n1.b + k4 * n1s.b, k2 * n1.c + k4 * n1s.c, 1.0 + (k2 * n1.d + k4 * n1s.d)};
+        }
+        const M2x2 n1m1 = mm(n1, m1);
+        P.p12 = {k1 * m1.a + k3 * n1m1.a, k1 * m1.b + k3 * n1m1.b, k1 * m1.c + k3 * n1m1.c, k1 * m1.d + k3 * n1m1.d};
+    }
+    {
+        const M2x2 n2 = mm(m2, m1);
+        {
+            const M2x2 n2s = mm(n2, n2);
+            P.p22 = {1.0 + (k2 * n2.a + k4 * n2s.a), k2 * n2.b + k4 * n2s.b, k2 * n2.c + k4 * n2s.c, 1.0 + (k2 * n2.d + k4 * n2s.d)};
+        }
+        const M2x2 n2m2 = mm(n2, m2);
+        P.p21 = {k1 * m2.a + k3 * n2m2.a, k1 * m2.b + k3 * n2m2.b, k1 * m2.c + k3 * n2m2.c, k1 * m2.d + k3 * n2m2.d};
+    }
     return P;
 }
 SD_HD __forceinline__ RProp prop_sq(const RProp &P)
