@@ -70,9 +70,19 @@ int pick_team(int B, int Lmax)
     int p2 = 1;
     while (p2 * 2 <= G) p2 *= 2;
     G = p2;
-    // working stack of 256/G teams must fit LDS; keep <= 80 KB so two workgroups share a CU
-    while (G < 64 && sd::phase_lds_bytes(Lmax, G) > 80u * 1024u) G *= 2;
+    // working stack of 256/G teams must fit LDS; keep <= 80 KB so two workgroups share a CU (the
+    // ellipticity snapshot slot is dropped for stacks this deep, see use_overlap)
+    while (G < 64 && sd::phase_lds_bytes(Lmax, G, false) > 80u * 1024u) G *= 2;
     return G;
+}
+
+// The second LDS slot (ellipticity of period k evaluated inside the first scan pass of period k+1) saves
+// one pass per period but doubles the workgroup's LDS: only while that leaves >= 4 workgroups per CU.
+static bool use_overlap(int Lmax, int G)
+{
+    size_t cap = 40u * 1024u;
+    if (const char *e = getenv("SURFDISP_OVERLAP_MAX")) cap = (size_t)atol(e);
+    return G >= 4 && sd::phase_lds_bytes(Lmax, G, true) <= cap;
 }
 
 int check_args(int B, int Lmax, int P, int kind, const void *model, const void *per,
@@ -167,7 +177,8 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     float wtol = 1.2e-3f, atol = 1.0e-6f;
     if (const char *e = getenv("SURFDISP_WTOL")) wtol = (float)atof(e);
     if (const char *e = getenv("SURFDISP_ATOL")) atol = (float)atof(e);
-    sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, status, wtol, atol, fastscan ? 1 : 0};
+    sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, status, wtol, atol, fastscan ? 1 : 0,
+                      use_overlap(Lmax, G) ? 1 : 0};
     SD_HIP(sd::launch_phase(s, kind, G, indep, ph));
     if (ev) SD_HIP(hipEventRecord(ev[2], s));
     sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, g_dbg, kb, ka, kr};

@@ -29,6 +29,7 @@ struct PhaseArgs {
     float wtol;           // bracket width below which the root may be read off by interpolation
     float atol;           // ... provided secant and 3-point estimates agree to this (km/s)
     int fast;             // SURFDISP_FASTSCAN: certified coarse-to-fine scan
+    int overlap;          // second LDS slot: the ellipticity passes ride in the next period's first scan pass
 };
 
 struct GroupArgs {
@@ -64,7 +65,7 @@ struct LayersArgs {
 hipError_t launch_layers(hipStream_t s, const LayersArgs &a, int L);
 hipError_t launch_thermal(hipStream_t s, const LayersArgs &a);
 
-size_t phase_lds_bytes(int Lmax, int G);
+size_t phase_lds_bytes(int Lmax, int G, bool overlap);
 hipError_t launch_finish(hipStream_t s, const FinishArgs &a);
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a);
 hipError_t launch_phase(hipStream_t s, int kind, int G, bool independent, const PhaseArgs &a);

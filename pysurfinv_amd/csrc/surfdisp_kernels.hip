@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
     float *wq = w_lds + slot;
     // second slot: a snapshot of the layers the ellipticity recursion of period k still needs while
     // the main slot already holds period k+1 (only for teams of >= 4 lanes, see OVERLAP below)
-    constexpr bool OVERLAP = (KIND == 2) && (G >= 4) && !INDEP;
+    const bool OVERLAP = (KIND == 2) && (G >= 4) && !INDEP && (A.overlap != 0);
     float *wq2 = w_lds + (size_t)NFW * Lcap * S + slot;
     const float *__restrict__ mdl = A.mdl;
     const size_t fs = (size_t)Lcap * B;
@@ -1444,7 +1444,7 @@ template <int KIND, int G, bool INDEP, bool FAST = false>
 hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 {
     constexpr int S = 256 / G;
-    const size_t lds = sd::phase_lds_bytes(a.Lmax, G);
+    const size_t lds = sd::phase_lds_bytes(a.Lmax, G, a.overlap != 0);
     auto kern = sd::surfdisp_phase_kernel<KIND, G, INDEP, FAST>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1484,7 +1484,7 @@ namespace sd {
 
 // working stack per team (+ the ellipticity snapshot slot for teams of >= 4 lanes; allocated for
 // Love too so that one number describes a launch)
-size_t phase_lds_bytes(int Lmax, int G) { return (size_t)(G >= 4 ? 2 : 1) * NFW * Lmax * (256 / G) * sizeof(float); }
+size_t phase_lds_bytes(int Lmax, int G, bool overlap) { return (size_t)((G >= 4 && overlap) ? 2 : 1) * NFW * Lmax * (256 / G) * sizeof(float); }
 
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a)
 {
