@@ -58,10 +58,10 @@ int pick_team(int B, int Lmax)
         if (e) G = atoi(e);
     }
     if (G == 0) {
-        // measured on MI355X: large batches want ~4 wavefronts per SIMD
-        // (262 144 lanes on 256 CUs x 4 SIMDs), mid-size ones ~2, tiny ones a whole wavefront per
-        // stack (latency); never fewer than 2 lanes per stack
-        const long target = (B >= 32768) ? 262144L : 131072L;
+        // measured on MI355X (scripts/dev_overlap.py): batches of 16 384 stacks and
+        // more want ~4 wavefronts per SIMD (262 144 lanes on 256 CUs x 4 SIMDs), smaller ones ~2, tiny
+        // ones a whole wavefront per stack (latency); never fewer than 2 lanes per stack
+        const long target = (B >= 16384) ? 262144L : 131072L;
         G = 2;
         while (G < 64 && (long)B * G < target) G *= 2;
     }
@@ -77,10 +77,11 @@ int pick_team(int B, int Lmax)
 }
 
 // The second LDS slot (ellipticity of period k evaluated inside the first scan pass of period k+1) saves
-// one pass per period but doubles the workgroup's LDS: only while that leaves >= 4 workgroups per CU.
+// one pass per period but doubles the workgroup's LDS: only while two workgroups still fit a CU
+// (measured: on at 49 KB is 7-19 % faster than off, on at 74 KB / 147 KB is 9 % / 38 % slower).
 static bool use_overlap(int Lmax, int G)
 {
-    size_t cap = 40u * 1024u;
+    size_t cap = 64u * 1024u;
     if (const char *e = getenv("SURFDISP_OVERLAP_MAX")) cap = (size_t)atol(e);
     return G >= 4 && sd::phase_lds_bytes(Lmax, G, true) <= cap;
 }

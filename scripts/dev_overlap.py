@@ -10,9 +10,9 @@ per = torch.from_numpy(synth.default_periods(20)).cuda()
 for (B, Ln) in ((65536, 10), (32768, 20), (16384, 32), (8192, 64), (25600, 96)):
     model = torch.from_numpy(synth.synth_models(B, Ln, seed=0)).cuda()
     plan = forward.BatchPlan(B, Ln, 20)
-    for cap in ("40960", "1000000"):
+    for cap in os.environ.get("CAPS", "65536").split(","):
         os.environ["SURFDISP_OVERLAP_MAX"] = cap
-        for team in (0, 4, 8, 16, 32):
+        for team in [int(x) for x in os.environ.get("TEAMS", "0,4,8,16,32").split(",")]:
             if L.surfdisp_set_team(team) != 0: continue
             try:
                 plan.run(model, per, kind=2 | 0x10); torch.cuda.synchronize()
