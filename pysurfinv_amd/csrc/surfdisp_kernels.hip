@@ -468,7 +468,10 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
     float *wq = w_lds + slot;
     // second slot: a snapshot of the layers the ellipticity recursion of period k still needs while
     // the main slot already holds period k+1 (only for teams of >= 4 lanes, see OVERLAP below)
-    const bool OVERLAP = (KIND == 2) && (G >= 4) && !INDEP && (A.overlap != 0);
+    // the ellipticity (two more recursions per period, surfa.f:360-363) only feeds the group-velocity
+    // kernel: a phase-only call (A.ratio == nullptr) skips it altogether
+    const bool want_ratio = (KIND == 2) && (A.ratio != nullptr);
+    const bool OVERLAP = want_ratio && (G >= 4) && !INDEP && (A.overlap != 0);
     float *wq2 = w_lds + (size_t)NFW * Lcap * S + slot;
     const float *__restrict__ mdl = A.mdl;
     const size_t fs = (size_t)Lcap * B;
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
                 if (!(w > 1.0e-6f) || (!(w > A.wtol) && agree) || passes > 64) {
                     croot = p0c + (inside ? t : ts);
                     if (croot <= W_B(mm_frozen - 1)) {             // calcul.f:191
-                        if (KIND == 2) {
+                        if (want_ratio) {
                             if (OVERLAP && k + 1 < P) {
                                 // snapshot the layers the ellipticity recursion reads, then move on:
                                 // the next build overwrites exactly these (first mm_frozen) layers
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
         if (solved) {
             if (j == 0) {
                 A.c[(size_t)k * B + b] = croot;                // period-major: coalesced across teams
-                if (KIND == 2 && !ell_pend) A.ratio[(size_t)k * B + b] = r12;
+                if (want_ratio && !ell_pend) A.ratio[(size_t)k * B + b] = r12;
             }
             nsolved = ++k;
             if (INDEP || k >= P) { st = ST_DONE; }
