@@ -50,7 +50,7 @@ Carve carve(void *base, int B, int Lmax, int P)
     return c;
 }
 
-int pick_team(int B, int Lmax)
+int pick_team(int B, int Lmax, bool need_ratio = true)
 {
     int G = g_team_override;
     if (G == 0) {
@@ -70,9 +70,11 @@ int pick_team(int B, int Lmax)
     int p2 = 1;
     while (p2 * 2 <= G) p2 *= 2;
     G = p2;
-    // working stack of 256/G teams must fit LDS; keep <= 80 KB so two workgroups share a CU (the
-    // ellipticity snapshot slot is dropped for stacks this deep, see use_overlap)
+    // working stack of 256/G teams must fit LDS so that two workgroups share a CU: with the ellipticity
+    // snapshot slot (Rayleigh c+U calls) both slots within 64 KB, without it (phase-only, Love) 80 KB
+    if (need_ratio) { while (G < 64 && G >= 4 && sd::phase_lds_bytes(Lmax, G, true) > 64u * 1024u) G *= 2; }
     while (G < 64 && sd::phase_lds_bytes(Lmax, G, false) > 80u * 1024u) G *= 2;
+    if (need_ratio) { while (G < 64 && G >= 4 && sd::phase_lds_bytes(Lmax, G, true) > 64u * 1024u) G *= 2; }
     return G;
 }
 
@@ -169,7 +171,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     // independent mode has B*P root searches in flight: size the teams for that many; a caller that
     // keeps a second batch in flight (SURFDISP_PIPELINED) has twice the stacks on the chip
     const long units = (indep ? (long)B * P : (long)B) * (pipelined ? 2 : 1);
-    const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax);
+    const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax, kind == SURFDISP_KIND_RAYLEIGH && !phase_only);
 
     sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl, P, indep ? w.nsolved : nullptr};
     if (ev) SD_HIP(hipEventRecord(ev[0], s));
