@@ -146,3 +146,74 @@ def analytic_kernels(model, periods, wtype="R", nlay=None, want_vp=True, want_rh
     vs = model[:, 1, :][:, None, :]
     phv = torch.where(h > 0, kb * vs / 100.0 / torch.where(h > 0, h, torch.ones_like(h)), torch.zeros_like(kb))
     return dict(dcdb=kb, dcda=ka, dcdr=kr, c0=c, u0=u, status=st, phv=phv)
+
+
+class SensKernelPert:
+    """Drop-in for the reference class of the same name (``senskernel.py:129-158``): ``model`` is a CSV
+    path or a pandas DataFrame with columns ``H``, ``Vs`` and either ``Vp``/``Rho``/``Qs`` or ``Grp``
+    (water / sediment / crust / mantle rules of ``sensModel._convert``, ``:104-124``).  After
+    construction ``kernel['Vs']`` (and ``kernel['Vp']`` when the frame has a ``Vp`` column) hold
+    float64 [n_periods, n_layers] arrays in the reference's units, (v(1.001 x) - v(0.999 x)) / 0.2 / H;
+    ``periods = range(Tmin, Tmax + Tstep//2, Tstep)``.
+
+    ``method='fd'`` reproduces the reference's finite differences (one batched solve of 2L+1 stacks per
+    column); ``method='analytic'`` takes the partials of one solve (``surfdisp_forward_kernels_device``)
+    and converts them, dc/dx * x / 100 / H - the same quantity without the fp32 differencing noise
+    (for a layer whose Vp/Rho/Qs follow from Vs through ``Grp``, the reference's Vs perturbation also moves
+    them; the analytic route applies that chain rule).  Love kernels use Love velocities (the reference
+    reads ``cr0`` for both wave types and returns ``None`` for Love, SURVEY.md section 4 defect 7)."""
+
+    def __init__(self, model, wtype="R", Tmin=20, Tmax=100, Tstep=10, dz=2, method="fd", device=0):
+        import pandas as pd
+        if isinstance(model, str):
+            df = pd.read_csv(model)
+        elif isinstance(model, pd.DataFrame):
+            df = model.copy()
+        else:
+            raise ValueError(f"Wrong model input: {model}")
+        self.df = df
+        self.wtype = wtype
+        self.periods = range(Tmin, Tmax + Tstep // 2, Tstep)
+        H = df["H"].to_numpy(float)
+        Vs = df["Vs"].to_numpy(float)
+        grp = list(df["Grp"]) if "Grp" in df else None
+        col = lambda k: df[k].to_numpy(float) if k in df else None
+        Vp, Rho, Qs = col("Vp"), col("Rho"), col("Qs")
+        self.H, self.Vs = H, Vs
+        self.kernel = {}
+        if method == "fd":
+            self.kernel["Vs"] = sens_kernel_pert(H, Vs, Vp, Rho, Qs, grp, self.periods, wtype, "Vs", device)["phv"]
+            if Vp is not None:
+                self.kernel["Vp"] = sens_kernel_pert(H, Vs, Vp, Rho, Qs, grp, self.periods, wtype, "Vp", device)["phv"]
+        elif method == "analytic":
+            import torch
+            dVp, dRho, dQs = (None, None, None) if grp is None else _derive(Vs, grp)
+            vp = Vp if Vp is not None else dVp
+            rho = Rho if Rho is not None else dRho
+            qs = Qs if Qs is not None else dQs
+            keep = H > 1e-3
+            m = np.stack([vp[keep], Vs[keep], rho[keep], H[keep], 1.0 / qs[keep]])[None].astype(np.float32)
+            dev = torch.device(f"cuda:{device}")
+            per = torch.as_tensor(np.asarray(list(self.periods), np.float32), device=dev)
+            out = analytic_kernels(torch.from_numpy(m).to(dev), per, wtype=wtype)
+            kb = out["dcdb"][0].double().cpu().numpy()
+            ka = out["dcda"][0].double().cpu().numpy() if out["dcda"] is not None else np.zeros_like(kb)
+            kr = out["dcdr"][0].double().cpu().numpy()
+            Hk, vsk, vpk = H[keep], Vs[keep], vp[keep]
+            dvp = np.zeros_like(vsk); drho = np.zeros_like(vsk)      # d(Vp, Rho)/dVs through the Grp rules
+            if grp is not None:
+                g = np.asarray(grp)[keep]
+                if Vp is None:
+                    dvp = np.select([g == "sediment", g == "crust", g == "mantle"], [1.23, 1.8, 1.76], 0.0)
+                if Rho is None:
+                    drho = np.select([g == "sediment", g == "crust", g == "mantle"],
+                                     [0.3601 * 1.23, 0.3601 * 1.8, 1.0 / 4.5], 0.0)
+            full = np.zeros((len(list(self.periods)), H.size))
+            full[:, keep] = (kb + ka * dvp[None, :] + kr * drho[None, :]) * vsk[None, :] / 100.0 / Hk[None, :]
+            self.kernel["Vs"] = full
+            if Vp is not None:
+                fullp = np.zeros_like(full)
+                fullp[:, keep] = ka * vpk[None, :] / 100.0 / Hk[None, :]
+                self.kernel["Vp"] = fullp
+        else:
+            raise ValueError("method must be 'fd' or 'analytic'")

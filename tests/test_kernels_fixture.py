@@ -163,3 +163,28 @@ def test_analytic_kernels_batch_rows_and_failures():
         c1, _, s1, kb1, _, _ = p1.run_kernels(torch.from_numpy(np.ascontiguousarray(m[i:i + 1, :, :n])).cuda(),
                                               torch.from_numpy(per).cuda(), kind=2)
         assert np.array_equal(kb[i, :, :n], kb1[0].cpu().numpy()) and not kb[i, :, n:].any()
+
+
+@pytest.mark.gpu
+def test_senskernelpert_class_fd_and_analytic_agree():
+    """Drop-in SensKernelPert: DataFrame in, kernel['Vs'] / kernel['Vp'] out (reference units); the
+    finite-difference route and the one-solve analytic route give the same kernels, also when Vp, Rho
+    follow from Vs through the group rules."""
+    import pandas as pd
+    from pysurfinv_amd import senskernel
+    H, Vs, Vp, Rho, Qs = eus_columns()
+    H = H.copy(); H[-1] = 50.0
+    df = pd.DataFrame(dict(H=H, Vs=Vs, Vp=Vp, Rho=Rho, Qs=Qs))
+    a = senskernel.SensKernelPert(df, wtype="R", method="fd")
+    b = senskernel.SensKernelPert(df, wtype="R", method="analytic")
+    assert list(a.periods) == list(range(20, 101, 10)) and a.kernel["Vs"].shape == (9, H.size)
+    thick = H >= 4.0
+    for key in ("Vs", "Vp"):
+        sc = np.abs(b.kernel[key][:, thick]).max()
+        assert np.abs(a.kernel[key][:, thick] - b.kernel[key][:, thick]).max() < 0.03 * sc, key   # fd noise
+    grp = ["sediment"] * 5 + ["crust"] * 8 + ["mantle"] * (H.size - 13)
+    dfg = pd.DataFrame(dict(H=H, Vs=Vs, Grp=grp))
+    a = senskernel.SensKernelPert(dfg, wtype="L", method="fd")
+    b = senskernel.SensKernelPert(dfg, wtype="L", method="analytic")
+    sc = np.abs(b.kernel["Vs"][:, thick]).max()
+    assert np.abs(a.kernel["Vs"][:, thick] - b.kernel["Vs"][:, thick]).max() < 0.03 * sc
