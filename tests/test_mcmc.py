@@ -173,3 +173,24 @@ def test_graphed_sampler_matches_plain_sampler_statistics():
                 state = tg[c, i, 3:]
     assert abs(tg[:, 1:, 2].mean() - tp[:, 1:, 2].mean()) < 0.05
     assert abs(np.median(tg[:, -1, 0]) / np.median(tp[:, -1, 0]) - 1) < 0.25
+
+
+def test_point_dropin_writes_reference_npz(tmp_path):
+    """pysurfinv_amd.point.Point: the reference's constructor / MCinvMP signature; the .npz carries the keys
+    and row layout point.py:82-85 writes (CPU run with the oracle forward injected)."""
+    from pysurfinv_amd import point as pt
+    per = G["trace/periods"]
+    p = pt.Point(CONT, localInfo={"note": 1}, periods=per, vels=G["trace/c_obs"], uncers=G["trace/uncer"], device="cpu")
+    assert p.setting["Info"]["note"] == 1 and p.initMod.spec.n == 13
+    fwd = oracle_forward(per.astype(np.float32))
+    p._sampler = lambda seed=None, **kw: MetropolisBatch(p.initMod.spec, p.initMod.to_model, per, G["trace/c_obs"],
+                                                         G["trace/uncer"], device="cpu", seed=seed, forward=fwd,
+                                                         **{k: v for k, v in kw.items() if k == "isgood"})
+    mis, chi, L = p.misfit()
+    assert abs(mis - G["trace/mcTrack"][0, 0]) < 2e-4 * mis          # the reference trace starts at the same model
+    arr = p.MCinvMP(outdir=str(tmp_path / "MCtest"), pid="7.0_3.0", runN=24, chainL=6, seed=1)
+    f = np.load(tmp_path / "MCtest" / "7.0_3.0.npz", allow_pickle=True)
+    assert f["mcTrack"].shape == (24, 16) and np.array_equal(f["mcTrack"], arr)
+    assert f["invMeta"][()] == {"pid": "7.0_3.0", "chainL": 6}
+    assert set(f["obs"][()].keys()) == {"T", "c", "uncer"} and "Crust" in f["setting"][()]
+    assert (arr[::6, 2] == 1).all()                                   # every chain's first row is "accepted"
