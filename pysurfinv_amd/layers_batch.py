@@ -498,6 +498,24 @@ class Model1DBatch:
             return self.to_model_native(params)
         return self.to_model_torch(params)
 
+    def forward(self, params=None, periods=(5, 10, 20, 40, 60, 80), wavetype="Ray"):
+        """``Model1D.forward(periods)`` (models.py:116-122) for every row of ``params`` (default: the
+        setting's own values): phase velocities float32 [B, P] through the HIP solver, rows of zeros where
+        the reference would return ``None``; status [B]."""
+        import numpy as _np
+        from . import _lib, forward as _fw
+        torch = self.torch
+        if self.device.type != "cuda":
+            raise _lib.SurfdispError("Model1DBatch.forward needs a HIP device (no CPU fallback)")
+        if params is None:
+            params = torch.as_tensor(self.spec.v0[None, :], dtype=torch.float64, device=self.device)
+        model, nlay = self.to_model(params)
+        per = torch.as_tensor(_np.asarray(periods, _np.float32), device=self.device)
+        kind = {"Ray": _lib.KIND_RAYLEIGH, "Love": _lib.KIND_LOVE}[wavetype] | _lib.PHASE_ONLY
+        plan = _fw.BatchPlan(model.shape[0], model.shape[2], per.numel(), device=self.device)
+        c, _, st = plan.run(model.contiguous(), per, kind=kind, nlay=nlay)
+        return c, st
+
     def to_model_torch(self, params):
         torch = self.torch
         (h, vs, vp, rho, qs, qp), nlay = self.seis_prop_layers(params)

@@ -148,6 +148,8 @@ def test_hybrid_stack_and_forward_on_gpu():
     per = torch.as_tensor(np.asarray(PERIODS, np.float32), device="cuda:0")
     c, u, st = forward_batch_torch(model, per, kind=2, nlay=nlay)
     assert int((st != 0).sum()) == 0
+    c2, st2 = mb.forward(params, PERIODS)                 # Model1D.forward() counterpart
+    assert torch.equal(c2, c) and int(st2.abs().sum()) == 0
     assert np.max(np.abs(c.cpu().numpy()[:6] - G["hyb_ritz/c"])) < 2e-5
     for kind in (1, 2):
         co, uo, so = cport.forward_batch(model.cpu().numpy(), np.asarray(PERIODS, np.float32), kind,
