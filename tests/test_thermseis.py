@@ -149,7 +149,7 @@ def test_hybrid_stack_and_forward_on_gpu():
     c, u, st = forward_batch_torch(model, per, kind=2, nlay=nlay)
     assert int((st != 0).sum()) == 0
     c2, st2 = mb.forward(params, PERIODS)                 # Model1D.forward() counterpart
-    assert torch.equal(c2, c) and int(st2.abs().sum()) == 0
+    assert float((c2 - c).abs().max()) < 5e-6 and int(st2.abs().sum()) == 0   # team sizes may differ (phase-only)
     assert np.max(np.abs(c.cpu().numpy()[:6] - G["hyb_ritz/c"])) < 2e-5
     for kind in (1, 2):
         co, uo, so = cport.forward_batch(model.cpu().numpy(), np.asarray(PERIODS, np.float32), kind,
