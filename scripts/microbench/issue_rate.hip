@@ -2,11 +2,13 @@
 // Rayleigh layer recursion (delta_rayleigh of surfdisp_kernels.hip, unchanged) sustain on gfx950 when
 // nothing else is in the way -- no state machine, no root search, every wavefront busy for the whole
 // launch?  Modes: 0 = every lane the same trial velocity (no divergence), 1 = lanes spread over
-// 3.0..4.4 km/s like the teams of the real kernel (evanescent / oscillatory S mixes inside a wave).
+// 3.0..4.4 km/s like the teams of the real kernel (evanescent / oscillatory S mixes inside a wave),
+// 2 = mode 1 with two independent evaluations per lane and iteration.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -I include -I pysurfinv_amd/csrc \
 //         scripts/microbench/issue_rate.hip -o gpurun_out/issue_rate && gpurun_out/issue_rate
 // Read the instruction count with:  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE -- gpurun_out/issue_rate
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "../../pysurfinv_amd/csrc/surfdisp_kernels.hip"
 
@@ -28,27 +30,41 @@ __global__ __launch_bounds__(256) void issue_kernel(float *out, int iters, int L
     __syncthreads();
     float c = (MODE == 0) ? 3.456f : 3.0f + 1.4f * (float)(slot % 16) / 16.0f + 0.01f * j;
     float acc = 0.0f;
-    for (int it = 0; it < iters; ++it) {
-        const float v = delta_rayleigh(wq, Lcap, S, L, c, T, 1);
-        acc += v;
-        c += (v > 1e30f) ? 1e-3f : 0.0f;                  // keeps the loop from being hoisted
+    if (MODE == 2) {
+        // two independent evaluations per lane and iteration (instruction-level parallelism 2)
+        float c2 = c + 0.005f;
+        for (int it = 0; it < iters / 2; ++it) {
+            const float v = delta_rayleigh(wq, Lcap, S, L, c, T, 1);
+            const float w = delta_rayleigh(wq, Lcap, S, L, c2, T, 1);
+            acc += v + w;
+            c += (v > 1e30f) ? 1e-3f : 0.0f;
+            c2 += (w > 1e30f) ? 1e-3f : 0.0f;
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+            const float v = delta_rayleigh(wq, Lcap, S, L, c, T, 1);
+            acc += v;
+            c += (v > 1e30f) ? 1e-3f : 0.0f;                  // keeps the loop from being hoisted
+        }
     }
     out[(size_t)blockIdx.x * 256 + tid] = acc;
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const int blocks = 1024, iters = 2000, L = 10;
+    const int blocks = argc > 1 ? atoi(argv[1]) : 1024;      // 1024 = 4 wavefronts per SIMD
+    const int iters = 2000, L = 10;
     float *out;
     hipMalloc(&out, (size_t)blocks * 256 * sizeof(float));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const size_t lds = (size_t)NFW * L * 64 * sizeof(float);
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 3; ++mode) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0, 0);
             if (mode == 0) hipLaunchKernelGGL(issue_kernel<0>, dim3(blocks), dim3(256), lds, 0, out, iters, L, 20.0f);
-            else           hipLaunchKernelGGL(issue_kernel<1>, dim3(blocks), dim3(256), lds, 0, out, iters, L, 20.0f);
+            else if (mode == 1) hipLaunchKernelGGL(issue_kernel<1>, dim3(blocks), dim3(256), lds, 0, out, iters, L, 20.0f);
+            else           hipLaunchKernelGGL(issue_kernel<2>, dim3(blocks), dim3(256), lds, 0, out, iters, L, 20.0f);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);
