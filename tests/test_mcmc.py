@@ -194,3 +194,21 @@ def test_point_dropin_writes_reference_npz(tmp_path):
     assert f["invMeta"][()] == {"pid": "7.0_3.0", "chainL": 6}
     assert set(f["obs"][()].keys()) == {"T", "c", "uncer"} and "Crust" in f["setting"][()]
     assert (arr[::6, 2] == 1).all()                                   # every chain's first row is "accepted"
+
+
+@pytest.mark.gpu
+def test_point_dropin_on_gpu(tmp_path):
+    """Point.MCinvMP end to end on the device (native parameters -> stack kernel, HIP forward, speculative
+    and fast-scan options): file written, chains inside the prior box, misfit of the start model as in the
+    reference trace."""
+    from pysurfinv_amd import point as pt
+    p = pt.Point(CONT, periods=G["trace/periods"], vels=G["trace/c_obs"], uncers=G["trace/uncer"], device="cuda:0")
+    mis, chi, L = p.misfit()
+    assert abs(mis - G["trace/mcTrack"][0, 0]) < 2e-4 * mis
+    arr = p.MCinvMP(outdir=str(tmp_path / "mc"), pid="1_2", runN=64 * 12, chainL=12, seed=3)
+    assert arr.shape == (64 * 12, 16) and np.isfinite(arr).all()
+    spec = p.initMod.spec
+    assert (arr[:, 3:] > spec.vmin).all() and (arr[:, 3:] < spec.vmax).all()
+    arr2 = p.MCinvMP(outdir=str(tmp_path / "mc"), pid="1_3", runN=64 * 12, chainL=12, seed=3, spec_depth=3, fastscan=True)
+    assert arr2.shape == arr.shape and np.isfinite(arr2).all()
+    assert os.path.exists(tmp_path / "mc" / "1_3.npz")
