@@ -12,14 +12,20 @@
 //                               40x per solve), validation.
 //   K1 surfdisp_phase_kernel  : phase velocities.  A TEAM of G lanes (G = 1..64, one wavefront holds
 //                               64/G teams) owns one stack; its period-dependent working stack
-//                               (a, b, rho, d) lives in LDS; every loop iteration each lane evaluates
-//                               the secular function at its own trial velocity with the 5-component
-//                               (Rayleigh) or 2-component (Love) recursion state in registers.
-//                               Periods are walked in order inside the team (faithful start rule
-//                               c1 = 0.9*c(k-1), mmax carry-over, failure guards: calcul.f:104-220).
+//                               (1/rho, b, rho, d, 1/a^2, 1/b^2 per layer) lives in LDS; every loop
+//                               iteration each lane evaluates the secular function at its own trial
+//                               velocity with the 5-component (Rayleigh) or 2-component (Love)
+//                               recursion state in registers.  Periods are walked in order inside the
+//                               team (faithful start rule c1 = 0.9*c(k-1), mmax carry-over, failure
+//                               guards, NaN semantics: calcul.f:104-220).  Template flags: INDEP (one
+//                               team per (stack, period), SURFDISP_INDEPENDENT), FAST (certified
+//                               coarse-to-fine scan, SURFDISP_FASTSCAN); phase-only calls skip the
+//                               ellipticity recursions.
 //   K2 surfdisp_group_kernel  : group velocities, one lane per (stack, period): eigenfunction
 //                               integration + energy integrals (surfa.f:714-1192 / 374-606), fp64 state
-//                               for Rayleigh as in the reference (surfa.f:717-722).
+//                               for Rayleigh as in the reference (surfa.f:717-722); the KERN
+//                               instantiation also writes the analytic partials dc/d(Vs, Vp, rho).
+//   K3 surfdisp_finish_kernel : period-major internal results -> the caller's [B][P] arrays.
 // No MFMA: the products are 5x5 / 4x4 / 2x2.  HBM traffic is one read of the model array and one
 // write of c/U; everything else is VALU + transcendental work.
 #include <hip/hip_runtime.h>
