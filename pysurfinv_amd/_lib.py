@@ -17,7 +17,7 @@ KIND_LOVE, KIND_RAYLEIGH = 1, 2
 PHASE_ONLY = 0x10
 INDEPENDENT = 0x20
 PIPELINED = 0x40
-FASTSCAN = 0x80
+EXACTSCAN = 0x80
 NPER_MAX, NLAY_MAX = 200, 200
 
 # every symbol include/surfdisp.h declares

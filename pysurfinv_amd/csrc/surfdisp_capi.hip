@@ -32,6 +32,7 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 struct Carve {
     float *mdl, *ratio, *ct, *ut;
     int *nl, *nsolved;
+    float *fsafe;
     size_t total;
 };
 
@@ -46,6 +47,7 @@ Carve carve(void *base, int B, int Lmax, int P)
     c.ut = reinterpret_cast<float *>(p + off);      off += align_up((size_t)P * B * sizeof(float));
     c.nl = reinterpret_cast<int *>(p + off);        off += align_up((size_t)B * sizeof(int));
     c.nsolved = reinterpret_cast<int *>(p + off);   off += align_up((size_t)B * sizeof(int));
+    c.fsafe = reinterpret_cast<float *>(p + off);   off += align_up((size_t)B * sizeof(float));
     c.total = off;
     return c;
 }
@@ -91,7 +93,7 @@ static bool use_overlap(int Lmax, int G)
 int check_args(int B, int Lmax, int P, int kind, const void *model, const void *per,
                const void *c, const void *u)
 {
-    const int wave = kind & ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED | SURFDISP_FASTSCAN);
+    const int wave = kind & ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED | SURFDISP_EXACTSCAN);
     if (B < 1 || Lmax < 2 || Lmax > SURFDISP_NLAY_MAX || P < 1 || P > SURFDISP_NPER_MAX ||
         (wave != SURFDISP_KIND_LOVE && wave != SURFDISP_KIND_RAYLEIGH) || !model || !per || !c ||
         (!u && !(kind & SURFDISP_PHASE_ONLY))) {
@@ -165,15 +167,15 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     const bool phase_only = (kind & SURFDISP_PHASE_ONLY) != 0;
     const bool indep = (kind & SURFDISP_INDEPENDENT) != 0;
     const bool pipelined = (kind & SURFDISP_PIPELINED) != 0;
-    const bool fastscan = (kind & SURFDISP_FASTSCAN) != 0;
-    kind &= ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED | SURFDISP_FASTSCAN);
+    const bool fastscan = (kind & SURFDISP_EXACTSCAN) == 0;     // certified coarse-to-fine scan unless opted out
+    kind &= ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED | SURFDISP_EXACTSCAN);
     const Carve w = carve(workspace, B, Lmax, P);
     // independent mode has B*P root searches in flight: size the teams for that many; a caller that
     // keeps a second batch in flight (SURFDISP_PIPELINED) has twice the stacks on the chip
     const long units = (indep ? (long)B * P : (long)B) * (pipelined ? 2 : 1);
     const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax, kind == SURFDISP_KIND_RAYLEIGH && !phase_only);
 
-    sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl, P, indep ? w.nsolved : nullptr};
+    sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl, P, indep ? w.nsolved : nullptr, w.fsafe};
     if (ev) SD_HIP(hipEventRecord(ev[0], s));
     SD_HIP(sd::launch_prep(s, kind, pa));
     if (ev) SD_HIP(hipEventRecord(ev[1], s));
@@ -181,7 +183,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     if (const char *e = getenv("SURFDISP_WTOL")) wtol = (float)atof(e);
     if (const char *e = getenv("SURFDISP_ATOL")) atol = (float)atof(e);
     sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, phase_only ? nullptr : w.ratio, w.nsolved, status, wtol, atol,
-                     fastscan ? 1 : 0, (!phase_only && use_overlap(Lmax, G)) ? 1 : 0};
+                     fastscan ? 1 : 0, w.fsafe, (!phase_only && use_overlap(Lmax, G)) ? 1 : 0};
     SD_HIP(sd::launch_phase(s, kind, G, indep, ph));
     if (ev) SD_HIP(hipEventRecord(ev[2], s));
     sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, g_dbg, kb, ka, kr};

@@ -15,6 +15,8 @@ struct PrepArgs {
     int *nl;              // [B] validated layer count, 0 = bad model
     int P;
     int *nsolved_init;    // nullptr, or [B]: set to P (independent mode reduces it with atomicMin)
+    float *fsafe;         // [B]: thickest layer (km) of a stack whose Vs and Vp never decrease with depth,
+                          // 1e30 otherwise (the scan then skips nothing on that stack)
 };
 
 struct PhaseArgs {
@@ -28,7 +30,8 @@ struct PhaseArgs {
     int *status;          // [B] or nullptr
     float wtol;           // bracket width below which the root may be read off by interpolation
     float atol;           // ... provided secant and 3-point estimates agree to this (km/s)
-    int fast;             // SURFDISP_FASTSCAN: certified coarse-to-fine scan
+    int fast;             // certified coarse-to-fine scan (the default; 0 with SURFDISP_EXACTSCAN)
+    const float *fsafe;   // [B], see PrepArgs
     int overlap;          // second LDS slot: the ellipticity passes ride in the next period's first scan pass
 };
 

@@ -19,7 +19,7 @@
 //                               team (faithful start rule c1 = 0.9*c(k-1), mmax carry-over, failure
 //                               guards, NaN semantics: calcul.f:104-220).  Template flags: INDEP (one
 //                               team per (stack, period), SURFDISP_INDEPENDENT), FAST (certified
-//                               coarse-to-fine scan, SURFDISP_FASTSCAN); phase-only calls skip the
+//                               coarse-to-fine scan; off with SURFDISP_EXACTSCAN); phase-only calls skip the
 //                               ellipticity recursions.
 //   K2 surfdisp_group_kernel  : group velocities, one lane per (stack, period): eigenfunction
 //                               integration + energy integrals (surfa.f:714-1192 / 374-606), fp64 state
@@ -73,6 +73,8 @@ SD_HD inline void prep_stack(const PrepArgs &A, const int b)
     bool ok = (n >= 2) && (n <= Lmax);
     const float pwr = pwr_of(KIND);
     const float apw = powr32(R0, pwr);
+    float hmax = 0.0f, vs_prev = 0.0f, vp_prev = 0.0f;
+    bool mono = true;
     if (ok) {
         float hs = 0.0f;          // running thickness sum, fp32 in layer order (flat1.f:33-37)
         float r_i = R0;           // radius of the top of layer i
@@ -83,6 +85,9 @@ SD_HD inline void prep_stack(const PrepArgs &A, const int b)
             if (!(fin(vp) && fin(vs) && fin(rho) && fin(h) && fin(qs)) ||
                 !(vp > 0.0f) || !(rho > 0.0f) || (vs < 0.0f) || (h < 0.0f))
                 ok = false;
+            if (i < n - 1 && h > hmax) hmax = h;
+            if ((i > 0 && (vs < vs_prev || vp < vp_prev))) mono = false;
+            vs_prev = vs; vp_prev = vp;
             hs = hs + h;
             const float r_n = R0 - hs;                       // radius of the bottom of layer i
             float dif = 0.0f, qqq = 0.0f, dfl = 0.0f;
@@ -108,6 +113,7 @@ SD_HD inline void prep_stack(const PrepArgs &A, const int b)
         }
     }
     A.nl[b] = ok ? n : 0;          // 0 => BADMODEL: K1/K2 write zeros
+    if (A.fsafe) A.fsafe[b] = (ok && mono) ? hmax : 1.0e30f;
     if (A.nsolved_init) A.nsolved_init[b] = ok ? A.P : 0;      // independent mode: reduced with atomicMin
 }
 
@@ -453,7 +459,8 @@ enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3 };
 //   period, on a freshly built full stack.  P times more teams, P times shorter dependency chain:
 //   the mode for small batches; equal to the faithful mode to ~1e-6 on well-behaved (monotone)
 //   stacks, NOT on rough ones (defects 2 and 9) - the caller opts in.
-// FAST = true: SURFDISP_FASTSCAN (instantiated for teams of 2, 4 and 8 lanes only).
+// FAST = true: certified coarse-to-fine scan, the default (instantiated for teams of 2, 4 and 8 lanes
+// only); FAST = false: every grid point (SURFDISP_EXACTSCAN, and all larger teams).
 template <int KIND, int G, bool INDEP, bool FAST = false>
 __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
 {
@@ -495,11 +502,15 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
     bool p0ok = false;                 // p0d was computed with mm_frozen (usable for interpolation)
     bool first = true;
     int status = SURFDISP_OK;
-    // SURFDISP_FASTSCAN (teams of 2..8 lanes): after the first pass of a period the scan advances
+    // certified coarse-to-fine scan (teams of 2..8 lanes): after the first pass of a period the scan advances
     // FSTRIDE grid points per lane; an interval between two coarse points is skipped only if it is
     // certified free of sign changes (see below), otherwise its fine points are scanned as usual
     constexpr int FSTRIDE = 4;
     constexpr bool fastok = FAST && (G >= 2) && (G <= 8);
+    // ... and only on stacks where two modes cannot sit within one coarse interval: velocities that never
+    // decrease with depth (no channel waves) and no layer thicker than three wavelengths of the period at
+    // hand (overtones of a thick layer crowd together as (c T / 2h)^2)
+    const float fsafe = (fastok && team_valid) ? A.fsafe[b] : 1.0e30f;
     bool coarse = false;               // this pass scans on the coarse grid
     int fine_left = 1;                 // fine points still to scan before going (back) to coarse
     float q0d = 0.0f; int q0mm = 0; bool q0ok = false;   // the coarse point before p0 (for lane 0)
@@ -696,7 +707,7 @@ __global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
                 if (passes > 100000) failed = true;            // cannot happen: c grows by dc/pass
                 if (fastok) {
                     fine_left -= had_ell ? G - 2 : G;
-                    if (fine_left <= 0) { coarse = true; q0ok = false; }
+                    if (fine_left <= 0 && fsafe <= 3.0f * p0c * T) { coarse = true; q0ok = false; }
                 }
             }
         } else if (st == ST_REFINE) {
@@ -1467,7 +1478,7 @@ hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 template <int KIND, bool INDEP>
 hipError_t launch_phase_k(hipStream_t s, const sd::PhaseArgs &a, int G)
 {
-    if (a.fast) {                                  // SURFDISP_FASTSCAN: teams of 2..8 lanes; others ignore it
+    if (a.fast) {                                  // certified coarse-to-fine scan: teams of 2..8 lanes only
         switch (G) {
             case 2:  return launch_phase_g<KIND, 2, INDEP, true>(s, a);
             case 4:  return launch_phase_g<KIND, 4, INDEP, true>(s, a);

@@ -44,7 +44,7 @@ class MetropolisBatch:
     """
 
     def __init__(self, spec: ParamSpec, to_model, periods, c_obs, uncer, device="cuda:0",
-                 isgood=None, proposer=None, seed=None, forward=None, independent=False, fastscan=False):
+                 isgood=None, proposer=None, seed=None, forward=None, independent=False, exact_scan=False):
         import torch
         self.torch = torch
         self.device = torch.device(device)
@@ -63,8 +63,8 @@ class MetropolisBatch:
         # independent=True: period-parallel root search (SURFDISP_INDEPENDENT) - lower latency for few
         # chains; only for smooth parameterisations (no low-velocity roughness), see include/surfdisp.h
         self.independent = bool(independent)
-        # fastscan=True: certified coarse-to-fine scan (SURFDISP_FASTSCAN); same brackets on smooth stacks
-        self.fastscan = bool(fastscan)
+        # exact_scan=True: the reference's point-by-point scan (SURFDISP_EXACTSCAN)
+        self.exact_scan = bool(exact_scan)
         self.n_forward = 0
 
     # ------------------------------------------------------------------ forward + misfit
@@ -80,7 +80,7 @@ class MetropolisBatch:
         if self._plan is None or (self._plan.B, self._plan.L) != (C, L):
             self._plan = BatchPlan(C, L, self.periods.numel(), device=self.device)
         c, _, st = self._plan.run(model.contiguous(), self.periods, kind=_lib.KIND_RAYLEIGH | _lib.PHASE_ONLY,
-                                  nlay=nlay, independent=self.independent, fastscan=self.fastscan)
+                                  nlay=nlay, independent=self.independent, exact_scan=self.exact_scan)
         return c.to(torch.float64), st
 
     def misfit(self, params):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development: SURFDISP_FASTSCAN against the faithful scan - identical outputs? how much faster?"""
+"""Development: default (certified coarse-to-fine) scan against SURFDISP_EXACTSCAN - identical outputs? how much faster?"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,8 +15,8 @@ for name in sorted(cases):
     d = cases[name]
     for t in (2, 4, 8):
         L.surfdisp_set_team(t)
-        c0, u0, s0 = forward.forward_batch(d["model"], d["periods"], d["kind"])
-        c1, u1, s1 = forward.forward_batch(d["model"], d["periods"], d["kind"], fastscan=True)
+        c0, u0, s0 = forward.forward_batch(d["model"], d["periods"], d["kind"], exact_scan=True)
+        c1, u1, s1 = forward.forward_batch(d["model"], d["periods"], d["kind"])
         nd = int((c0 != c1).sum())
         tot += c0.size; dif += nd
         if nd:
@@ -32,8 +32,8 @@ for it in range(int(os.environ.get("FS_CASES", "60"))):
                            monotone=bool(rng.random() < 0.5), total_thickness=float(rng.choice([60., 120., 200.])))
     P = int(rng.integers(5, 30)); per = np.sort(rng.uniform(4.0, 120.0, P)).astype(np.float32)
     L.surfdisp_set_team(int(rng.choice([2, 4, 8])))
-    c0, u0, s0 = forward.forward_batch(m, per, kind)
-    c1, u1, s1 = forward.forward_batch(m, per, kind, fastscan=True)
+    c0, u0, s0 = forward.forward_batch(m, per, kind, exact_scan=True)
+    c1, u1, s1 = forward.forward_batch(m, per, kind)
     tot += c0.size; dif += int((c0 != c1).sum()); pat += int(((c0 > 0) != (c1 > 0)).any(axis=1).sum())
 print(f"random stacks: {dif} of {tot} phase velocities differ ({dif / tot:.2e}); stacks with a different zero pattern: {pat}")
 L.surfdisp_set_team(0)
@@ -44,10 +44,10 @@ for (B, Ln, kind) in ((65536, 10, 2), (65536, 10, 1), (8192, 64, 2)):
     plan = forward.BatchPlan(B, Ln, 20)
     for t in (0, 2):
         L.surfdisp_set_team(t)
-        for fs in (False, True):
-            plan.run(model, per, kind=kind | 0x10, fastscan=fs); torch.cuda.synchronize()
+        for fs in (True, False):
+            plan.run(model, per, kind=kind | 0x10, exact_scan=fs); torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(5): plan.run(model, per, kind=kind | 0x10, fastscan=fs)
+            for _ in range(5): plan.run(model, per, kind=kind | 0x10, exact_scan=fs)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
-            print(f"B={B} L={Ln} kind={kind} team={t} fastscan={fs}: phase-only {dt*1e3:7.2f} ms")
+            print(f"B={B} L={Ln} kind={kind} team={t} exact_scan={fs}: phase-only {dt*1e3:7.2f} ms")
 L.surfdisp_set_team(0)

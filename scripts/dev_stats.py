@@ -4,7 +4,7 @@
 pysurfinv_amd/lib/libsurfdisp_stats.so; not part of the product build.  r01g, bench workload:
   team 2: scan 19.2 passes, refine 1.28, ellipticity 1.00 per period (43 evaluations; reference 52)
   team 4: scan 10.4, refine 1.07, ellipticity 0.05 (rides in the next scan pass)   (48 evaluations)
-  team 2 + SURFDISP_FASTSCAN: scan 9.5;  team 4 + FASTSCAN: scan 6.3."""
+  default (certified coarse-to-fine) scan: team 2 scan 9.5 passes, team 4 scan 6.3; the figures above are SURFDISP_EXACTSCAN."""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,12 +19,12 @@ per = torch.from_numpy(synth.default_periods(20)).cuda()
 model = torch.from_numpy(synth.synth_models(65536, 10, seed=0)).cuda()
 plan = forward.BatchPlan(65536, 10, 20)
 for team in (2, 4, 8):
-    for fs in (False, True):
+    for fs in (True, False):
         L.surfdisp_set_team(team)
         L.surfdisp_stats(None, 1)
-        plan.run(model, per, kind=2, fastscan=fs); torch.cuda.synchronize()
+        plan.run(model, per, kind=2, exact_scan=fs); torch.cuda.synchronize()
         out = (ctypes.c_ulonglong * 8)()
         L.surfdisp_stats(out, 0)
         s = np.array(list(out), float)
         n = s[4]
-        print(f"team {team} fastscan {fs}: per solved period: scan passes {s[0]/n:.2f}, refine {s[1]/n:.2f}, ellip {s[2]/n:.2f}; evaluations/period ~ {(s[0]+s[1])*team/n + 2:.1f}")
+        print(f"team {team} exact_scan {fs}: per solved period: scan passes {s[0]/n:.2f}, refine {s[1]/n:.2f}, ellip {s[2]/n:.2f}; evaluations/period ~ {(s[0]+s[1])*team/n + 2:.1f}")

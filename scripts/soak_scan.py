@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU-only soak: SURFDISP_FASTSCAN against the faithful scan, bit for bit, on random stacks.
+"""GPU-only soak: the default (certified coarse-to-fine) scan against SURFDISP_EXACTSCAN, bit for bit, on random stacks.
 SOAK_MONO=1: monotone stacks only (Vs, Vp non-decreasing with depth)."""
 import os, sys, time
 import numpy as np
@@ -27,8 +27,8 @@ while time.time() < T_END:
     team = int(rng.choice([2, 4, 8])); L.surfdisp_set_team(team)
     md = torch.from_numpy(m).cuda(); pd = torch.from_numpy(per).cuda()
     plan = forward.BatchPlan(B, Ln, P)
-    c0, u0, s0 = plan.run(md, pd, kind=kind | 0x10); c0 = c0.clone(); s0 = s0.clone()
-    c1, u1, s1 = plan.run(md, pd, kind=kind | 0x10, fastscan=True)
+    c0, u0, s0 = plan.run(md, pd, kind=kind | 0x10, exact_scan=True); c0 = c0.clone(); s0 = s0.clone()
+    c1, u1, s1 = plan.run(md, pd, kind=kind | 0x10)
     d = (c0 != c1)
     nd = int(d.sum()); ndif += nd; nval += c0.numel(); nst += B; ncase += 1
     npat += int(((c0 > 0) != (c1 > 0)).any(dim=1).sum())
@@ -38,7 +38,7 @@ while time.time() < T_END:
         T_LAST = time.time()
         print(f"  ... {ncase} cases, {nst} stacks, {nval} phase velocities, {ndif} differ, {npat} stacks with another zero pattern", flush=True)
 L.surfdisp_set_team(0)
-print(f"fastscan soak (monotone only: {MONO}): {ncase} cases, {nst} stacks, {nval} phase velocities; {ndif} differ ({ndif / max(nval, 1):.2e}); "
+print(f"scan soak, default vs exact (monotone only: {MONO}): {ncase} cases, {nst} stacks, {nval} phase velocities; {ndif} differ ({ndif / max(nval, 1):.2e}); "
       f"{npat} stacks with a different zero pattern")
 for w in sorted(worst, reverse=True)[:15]:
     print("   differ %d: L=%d kind=%d noise=%.2f thick=%.0f P=%d team=%d max|dc|=%.2e" % w)

@@ -20,12 +20,15 @@ SIMDS = 1024
 
 
 def short(name):
-    """Kernel family of a trace/counter row; the opt-in instantiations (SURFDISP_FASTSCAN root search,
-    group kernel with analytic partials: last template argument true) are kept out of the summary."""
+    """Kernel family of a trace/counter row.  Kept out of the summary: the SURFDISP_EXACTSCAN root search
+    (last template argument false; the default, certified scan is <..., true>) and the group kernel with
+    analytic partials (last template argument true)."""
     for k in KERNELS:
         if k in name:
             targs = name.split("<")[-1].split(">")[0].replace(" ", "")
-            if k in ("surfdisp_phase_kernel", "surfdisp_group_kernel") and targs.endswith("true"):
+            if k == "surfdisp_phase_kernel" and targs.endswith("false"):
+                return None
+            if k == "surfdisp_group_kernel" and targs.endswith("true"):
                 return None
             return k
     return None

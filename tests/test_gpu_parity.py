@@ -399,38 +399,38 @@ def test_fp32_overflow_fails_the_stack_like_the_reference(hip):
 
 
 @pytest.mark.parametrize("team", [2, 4, 8, 64])
-def test_fastscan_same_brackets_on_golden_cases(hip, ref_cases, team):
-    """SURFDISP_FASTSCAN (opt-in): coarse steps over certified intervals, point-by-point rescans
-    elsewhere - on every golden case, the rough ones included, the outputs are bit-identical to the
-    faithful scan (teams above 8 lanes ignore the flag)."""
+def test_default_scan_same_brackets_as_exact_scan_on_golden_cases(hip, ref_cases, team):
+    """Default scan (coarse steps over certified intervals, point-by-point rescans elsewhere) against
+    SURFDISP_EXACTSCAN (every grid point, as the reference): bit-identical outputs on every golden case,
+    the rough ones included (teams above 8 lanes always scan exactly)."""
     from pysurfinv_amd import _lib
     assert _lib.lib().surfdisp_set_team(team) == 0
     try:
         for name, d in ref_cases.items():
-            c0, u0, s0 = hip.forward_batch(d["model"], d["periods"], d["kind"])
-            c1, u1, s1 = hip.forward_batch(d["model"], d["periods"], d["kind"], fastscan=True)
+            c0, u0, s0 = hip.forward_batch(d["model"], d["periods"], d["kind"], exact_scan=True)
+            c1, u1, s1 = hip.forward_batch(d["model"], d["periods"], d["kind"])
             assert np.array_equal(c0, c1) and np.array_equal(s0, s1), name
             assert np.array_equal(u0, u1, equal_nan=True), name
     finally:
         _lib.lib().surfdisp_set_team(0)
 
 
-def test_fastscan_random_smooth_stacks_and_independent_mode(hip):
-    """Smooth random stacks (noise <= 0.1, with and without low-velocity layers): identical to the
-    faithful scan; also composes with SURFDISP_INDEPENDENT."""
+def test_default_scan_random_stacks_and_independent_mode(hip):
+    """Random stacks (smooth and rough, with and without low-velocity layers, thin and thick): the
+    default scan is bit-identical to SURFDISP_EXACTSCAN; also under SURFDISP_INDEPENDENT."""
     from pysurfinv_amd import synth, _lib
     rng = np.random.default_rng(8)
-    for it in range(8):
+    for it in range(12):
         L = int(rng.integers(3, 30))
-        m = synth.synth_models(1024, L, seed=int(rng.integers(1 << 30)), noise=float(rng.choice([0.02, 0.05, 0.1])),
-                               monotone=bool(it % 2), total_thickness=float(rng.choice([60., 120., 200.])))
+        m = synth.synth_models(1024, L, seed=int(rng.integers(1 << 30)), noise=float(rng.choice([0.02, 0.05, 0.1, 0.2])),
+                               monotone=bool(it % 2), total_thickness=float(rng.choice([30., 60., 120., 200., 400.])))
         per = np.sort(rng.uniform(4.0, 120.0, int(rng.integers(5, 30)))).astype(np.float32)
         kind = 1 + it % 2
-        c0, u0, s0 = hip.forward_batch(m, per, kind)
-        c1, u1, s1 = hip.forward_batch(m, per, kind, fastscan=True)
+        c0, u0, s0 = hip.forward_batch(m, per, kind, exact_scan=True)
+        c1, u1, s1 = hip.forward_batch(m, per, kind)
         assert np.array_equal(c0, c1) and np.array_equal(s0, s1) and np.array_equal(u0, u1, equal_nan=True)
     m = synth.synth_models(512, 10, seed=1)
     per = synth.default_periods(20)
-    c0, u0, s0 = hip.forward_batch(m, per, 2, independent=True)
-    c1, u1, s1 = hip.forward_batch(m, per, 2, independent=True, fastscan=True)
+    c0, u0, s0 = hip.forward_batch(m, per, 2, independent=True, exact_scan=True)
+    c1, u1, s1 = hip.forward_batch(m, per, 2, independent=True)
     assert np.array_equal(c0, c1) and np.array_equal(s0, s1)

@@ -199,7 +199,7 @@ def test_point_dropin_writes_reference_npz(tmp_path):
 @pytest.mark.gpu
 def test_point_dropin_on_gpu(tmp_path):
     """Point.MCinvMP end to end on the device (native parameters -> stack kernel, HIP forward, speculative
-    and fast-scan options): file written, chains inside the prior box, misfit of the start model as in the
+    and exact-scan options): file written, chains inside the prior box, misfit of the start model as in the
     reference trace."""
     from pysurfinv_amd import point as pt
     p = pt.Point(CONT, periods=G["trace/periods"], vels=G["trace/c_obs"], uncers=G["trace/uncer"], device="cuda:0")
@@ -209,6 +209,6 @@ def test_point_dropin_on_gpu(tmp_path):
     assert arr.shape == (64 * 12, 16) and np.isfinite(arr).all()
     spec = p.initMod.spec
     assert (arr[:, 3:] > spec.vmin).all() and (arr[:, 3:] < spec.vmax).all()
-    arr2 = p.MCinvMP(outdir=str(tmp_path / "mc"), pid="1_3", runN=64 * 12, chainL=12, seed=3, spec_depth=3, fastscan=True)
+    arr2 = p.MCinvMP(outdir=str(tmp_path / "mc"), pid="1_3", runN=64 * 12, chainL=12, seed=3, spec_depth=3, exact_scan=True)
     assert arr2.shape == arr.shape and np.isfinite(arr2).all()
     assert os.path.exists(tmp_path / "mc" / "1_3.npz")
