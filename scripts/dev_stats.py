@@ -4,7 +4,9 @@
 pysurfinv_amd/lib/libsurfdisp_stats.so; not part of the product build.  r01g, bench workload:
   team 2: scan 19.2 passes, refine 1.28, ellipticity 1.00 per period (43 evaluations; reference 52)
   team 4: scan 10.4, refine 1.07, ellipticity 0.05 (rides in the next scan pass)   (48 evaluations)
-  default (certified coarse-to-fine) scan: team 2 scan 9.5 passes, team 4 scan 6.3; the figures above are SURFDISP_EXACTSCAN."""
+  default (certified coarse-to-fine) scan: team 2 scan 9.5 passes (5.2 coarse), team 4 scan 6.3 (3.4 coarse); a coarse pass
+  ends on the true sign change (1.0 per period), on the curvature test just before it (0.8) or on a change of the
+  layer dropping (0.06); the figures above are SURFDISP_EXACTSCAN."""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,8 +25,11 @@ for team in (2, 4, 8):
         L.surfdisp_set_team(team)
         L.surfdisp_stats(None, 1)
         plan.run(model, per, kind=2, exact_scan=fs); torch.cuda.synchronize()
-        out = (ctypes.c_ulonglong * 8)()
+        out = (ctypes.c_ulonglong * 16)()
         L.surfdisp_stats(out, 0)
         s = np.array(list(out), float)
         n = s[4]
-        print(f"team {team} exact_scan {fs}: per solved period: scan passes {s[0]/n:.2f}, refine {s[1]/n:.2f}, ellip {s[2]/n:.2f}; evaluations/period ~ {(s[0]+s[1])*team/n + 2:.1f}")
+        print(f"team {team} exact_scan {fs}: per solved period: scan passes {s[0]/n:.2f} (coarse {s[5]/n:.2f}, of which ended by an "
+              f"uncertified interval {s[6]/n:.2f}), refine {s[1]/n:.2f}, ellip {s[2]/n:.2f}; evaluations/period ~ {(s[0]+s[1])*team/n + 2:.1f}"
+              + (f"; coarse-pass endings per period: sign change {s[9]/n:.2f}, guard {s[10]/n:.2f}, near half space {s[11]/n:.2f}, "
+                 f"layer dropping changed {s[12]/n:.2f}, curvature {s[13]/n:.2f}" if s[5] else ""))
