@@ -74,9 +74,10 @@ int pick_team(int B, int Lmax, bool need_ratio = true)
     G = p2;
     // working stack of 256/G teams must fit LDS so that two workgroups share a CU: with the ellipticity
     // snapshot slot (Rayleigh c+U calls) both slots within 64 KB, without it (phase-only, Love) 80 KB
-    if (need_ratio) { while (G < 64 && G >= 4 && sd::phase_lds_bytes(Lmax, G, true) > 64u * 1024u) G *= 2; }
-    while (G < 64 && sd::phase_lds_bytes(Lmax, G, false) > 80u * 1024u) G *= 2;
-    if (need_ratio) { while (G < 64 && G >= 4 && sd::phase_lds_bytes(Lmax, G, true) > 64u * 1024u) G *= 2; }
+    const size_t per256 = 256 / SD_PHASE_BLOCK;        // the budgets below are per 256 lanes
+    if (need_ratio) { while (G < 64 && G >= 4 && sd::phase_lds_bytes(Lmax, G, true) * per256 > 64u * 1024u) G *= 2; }
+    while (G < 64 && sd::phase_lds_bytes(Lmax, G, false) * per256 > 80u * 1024u) G *= 2;
+    if (need_ratio) { while (G < 64 && G >= 4 && sd::phase_lds_bytes(Lmax, G, true) * per256 > 64u * 1024u) G *= 2; }
     return G;
 }
 
@@ -87,7 +88,7 @@ static bool use_overlap(int Lmax, int G)
 {
     size_t cap = 64u * 1024u;
     if (const char *e = getenv("SURFDISP_OVERLAP_MAX")) cap = (size_t)atol(e);
-    return G >= 4 && sd::phase_lds_bytes(Lmax, G, true) <= cap;
+    return G >= 4 && sd::phase_lds_bytes(Lmax, G, true) * (256 / SD_PHASE_BLOCK) <= cap;
 }
 
 int check_args(int B, int Lmax, int P, int kind, const void *model, const void *per,

@@ -68,7 +68,13 @@ struct LayersArgs {
 hipError_t launch_layers(hipStream_t s, const LayersArgs &a, int L);
 hipError_t launch_thermal(hipStream_t s, const LayersArgs &a);
 
-size_t phase_lds_bytes(int Lmax, int G, bool overlap);
+// lanes per workgroup of the root search.  Nothing in it synchronises across wavefronts, so any multiple of 64
+// works; measured with two batches in flight (M solves/s): 64 lanes 28.0, 128 30.8, 256 32.3, 512 32.7 - smaller
+// workgroups do NOT help the second batch in, they slow the pair down
+#ifndef SD_PHASE_BLOCK
+#define SD_PHASE_BLOCK 256
+#endif
+size_t phase_lds_bytes(int Lmax, int G, bool overlap);   // per workgroup of SD_PHASE_BLOCK lanes
 hipError_t launch_finish(hipStream_t s, const FinishArgs &a);
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a);
 hipError_t launch_phase(hipStream_t s, int kind, int G, bool independent, const PhaseArgs &a);

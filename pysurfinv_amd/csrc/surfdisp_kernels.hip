@@ -452,6 +452,7 @@ __device__ __forceinline__ int drop_layers(const float *wq, const int Lcap, cons
 // ================================================================================== K1: phase
 enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3 };
 
+
 // INDEP = false: "faithful" - a team owns a stack and walks its periods in order (reference
 //   semantics: start rule 0.9*c(k-1), mmax carry-over, failure cascade).
 // INDEP = true : "independent" - a team owns ONE (stack, period) root search (BASELINE north_star's
@@ -462,10 +463,10 @@ enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3 };
 // FAST = true: certified coarse-to-fine scan, the default (instantiated for teams of 2, 4 and 8 lanes
 // only); FAST = false: every grid point (SURFDISP_EXACTSCAN, and all larger teams).
 template <int KIND, int G, bool INDEP, bool FAST = false>
-__global__ __launch_bounds__(256) void surfdisp_phase_kernel(PhaseArgs A)
+__global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArgs A)
 {
     extern __shared__ float w_lds[];
-    constexpr int S = 256 / G;                 // stacks (teams) per workgroup
+    constexpr int S = SD_PHASE_BLOCK / G;                 // stacks (teams) per workgroup
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int slot = tid / G;
@@ -1463,7 +1464,7 @@ namespace {
 template <int KIND, int G, bool INDEP, bool FAST = false>
 hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 {
-    constexpr int S = 256 / G;
+    constexpr int S = SD_PHASE_BLOCK / G;
     const size_t lds = sd::phase_lds_bytes(a.Lmax, G, a.overlap != 0);
     auto kern = sd::surfdisp_phase_kernel<KIND, G, INDEP, FAST>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -1471,7 +1472,7 @@ hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
     if (e != hipSuccess) return e;
     const long teams = INDEP ? (long)a.B * a.P : (long)a.B;
     const int grid = (int)((teams + S - 1) / S);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SD_PHASE_BLOCK), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1504,7 +1505,7 @@ namespace sd {
 
 // working stack per team (+ the ellipticity snapshot slot for teams of >= 4 lanes; allocated for
 // Love too so that one number describes a launch)
-size_t phase_lds_bytes(int Lmax, int G, bool overlap) { return (size_t)((G >= 4 && overlap) ? 2 : 1) * NFW * Lmax * (256 / G) * sizeof(float); }
+size_t phase_lds_bytes(int Lmax, int G, bool overlap) { return (size_t)((G >= 4 && overlap) ? 2 : 1) * NFW * Lmax * (SD_PHASE_BLOCK / G) * sizeof(float); }
 
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a)
 {
