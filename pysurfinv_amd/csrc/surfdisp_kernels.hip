@@ -686,7 +686,10 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
             ++passes;
             if (fl >= 0) {                                     // rescan this interval point by point
                 p0c = e_pc; p0d = e_pd; p0mm = e_pmm;
-                coarse = false; fine_left = FSTRIDE; q0ok = false;
+                // an interval that merely failed the certificate usually sits just below the root (the
+                // smaller end value is what the curvature is compared with): stay on the fine grid for
+                // the next interval too instead of spending a coarse pass on finding the sign change there
+                coarse = false; fine_left = e_cross ? FSTRIDE : 2 * FSTRIDE; q0ok = false;
             } else {
                 q0d = pl_d; q0mm = pl_mm; q0ok = true;
                 p0c = l_c; p0d = l_d; p0mm = l_mm;
