@@ -973,10 +973,12 @@ SD_HD __forceinline__ void prop_apply(const RProp &P, double v[4])
 {
 #pragma clang fp contract(off)
     const double ur = v[0], uz = v[1], tz = v[2], tr = v[3];
-    v[0] = fma(P.p11.a, ur, P.p11.b * tz) + fma(P.p12.a, uz, P.p12.b * tr);
-    v[2] = fma(P.p11.c, ur, P.p11.d * tz) + fma(P.p12.c, uz, P.p12.d * tr);
-    v[1] = fma(P.p21.a, ur, P.p21.b * tz) + fma(P.p22.a, uz, P.p22.b * tr);
-    v[3] = fma(P.p21.c, ur, P.p21.d * tz) + fma(P.p22.c, uz, P.p22.d * tr);
+    // one multiply and three fused multiply-adds per row (fp64 runs at half rate: the applications of P
+    // are most of this kernel's time); every sweep uses this same routine, so they stay bit-consistent
+    v[0] = fma(P.p11.a, ur, fma(P.p11.b, tz, fma(P.p12.a, uz, P.p12.b * tr)));
+    v[2] = fma(P.p11.c, ur, fma(P.p11.d, tz, fma(P.p12.c, uz, P.p12.d * tr)));
+    v[1] = fma(P.p21.a, ur, fma(P.p21.b, tz, fma(P.p22.a, uz, P.p22.b * tr)));
+    v[3] = fma(P.p21.c, ur, fma(P.p21.d, tz, fma(P.p22.c, uz, P.p22.d * tr)));
 }
 
 // integrate both solutions from the half space to the surface.  INTEG = false: only the surface
