@@ -919,6 +919,15 @@ SD_HD __forceinline__ M2x2 mm(const M2x2 &x, const M2x2 &y)
     r.c = fma(x.c, y.a, x.d * y.c); r.d = fma(x.c, y.b, x.d * y.d);
     return r;
 }
+// x y + u v, one multiply and three fma per element
+SD_HD __forceinline__ M2x2 mm2(const M2x2 &x, const M2x2 &y, const M2x2 &u, const M2x2 &v)
+{
+#pragma clang fp contract(off)
+    M2x2 r;
+    r.a = fma(x.a, y.a, fma(x.b, y.c, fma(u.a, v.a, u.b * v.c))); r.b = fma(x.a, y.b, fma(x.b, y.d, fma(u.a, v.b, u.b * v.d)));
+    r.c = fma(x.c, y.a, fma(x.d, y.c, fma(u.c, v.a, u.d * v.c))); r.d = fma(x.c, y.b, fma(x.d, y.d, fma(u.c, v.b, u.d * v.d)));
+    return r;
+}
 SD_HD __forceinline__ M2x2 madd(const M2x2 &x, const M2x2 &y)
 {
     M2x2 r; r.a = x.a + y.a; r.b = x.b + y.b; r.c = x.c + y.c; r.d = x.d + y.d; return r;
@@ -943,29 +952,29 @@ SD_HD __forceinline__ RProp make_prop(const RCoef &q)
         const M2x2 n1 = mm(m1, m2);
         {
             const M2x2 n1s = mm(n1, n1);
-            P.p11 = {1.0 + (k2 * n1.a + k4 * n1s.a), k2 * n1.b + k4 * n1s.b, k2 * n1.c + k4 * n1s.c, 1.0 + (k2 * n1.d + k4 * n1s.d)};
+            P.p11 = {1.0 + fma(k2, n1.a, k4 * n1s.a), fma(k2, n1.b, k4 * n1s.b), fma(k2, n1.c, k4 * n1s.c), 1.0 + fma(k2, n1.d, k4 * n1s.d)};
         }
         const M2x2 n1m1 = mm(n1, m1);
-        P.p12 = {k1 * m1.a + k3 * n1m1.a, k1 * m1.b + k3 * n1m1.b, k1 * m1.c + k3 * n1m1.c, k1 * m1.d + k3 * n1m1.d};
+        P.p12 = {fma(k1, m1.a, k3 * n1m1.a), fma(k1, m1.b, k3 * n1m1.b), fma(k1, m1.c, k3 * n1m1.c), fma(k1, m1.d, k3 * n1m1.d)};
     }
     {
         const M2x2 n2 = mm(m2, m1);
         {
             const M2x2 n2s = mm(n2, n2);
-            P.p22 = {1.0 + (k2 * n2.a + k4 * n2s.a), k2 * n2.b + k4 * n2s.b, k2 * n2.c + k4 * n2s.c, 1.0 + (k2 * n2.d + k4 * n2s.d)};
+            P.p22 = {1.0 + fma(k2, n2.a, k4 * n2s.a), fma(k2, n2.b, k4 * n2s.b), fma(k2, n2.c, k4 * n2s.c), 1.0 + fma(k2, n2.d, k4 * n2s.d)};
         }
         const M2x2 n2m2 = mm(n2, m2);
-        P.p21 = {k1 * m2.a + k3 * n2m2.a, k1 * m2.b + k3 * n2m2.b, k1 * m2.c + k3 * n2m2.c, k1 * m2.d + k3 * n2m2.d};
+        P.p21 = {fma(k1, m2.a, k3 * n2m2.a), fma(k1, m2.b, k3 * n2m2.b), fma(k1, m2.c, k3 * n2m2.c), fma(k1, m2.d, k3 * n2m2.d)};
     }
     return P;
 }
 SD_HD __forceinline__ RProp prop_sq(const RProp &P)
 {
     RProp Q;
-    Q.p11 = madd(mm(P.p11, P.p11), mm(P.p12, P.p21));
-    Q.p12 = madd(mm(P.p11, P.p12), mm(P.p12, P.p22));
-    Q.p21 = madd(mm(P.p21, P.p11), mm(P.p22, P.p21));
-    Q.p22 = madd(mm(P.p21, P.p12), mm(P.p22, P.p22));
+    Q.p11 = mm2(P.p11, P.p11, P.p12, P.p21);
+    Q.p12 = mm2(P.p11, P.p12, P.p12, P.p22);
+    Q.p21 = mm2(P.p21, P.p11, P.p22, P.p21);
+    Q.p22 = mm2(P.p21, P.p12, P.p22, P.p22);
     return Q;
 }
 // v = (ur, uz, tz, tr)
