@@ -1087,16 +1087,18 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
             }
             const float hq = dz / 22.5f;
 #define SD_BOOLE(v) (hq * (7.0f * (v[0] + v[4]) + 32.0f * (v[1] + v[3]) + 12.0f * v[2]))
-            const double dmmr = SD_BOOLE(f_mr), dmmz = SD_BOOLE(f_mz);
-            const double drsz = SD_BOOLE(f_rz), dzsr = SD_BOOLE(f_zr);
+            const float dmmr = SD_BOOLE(f_mr), dmmz = SD_BOOLE(f_mz);
+            const float drsz = SD_BOOLE(f_rz), dzsr = SD_BOOLE(f_zr);
             if (kern) {
                 k_mr += dmmr; k_mz += dmmz; k_rz += drsz; k_zr += dzsr;
                 k_sz += SD_BOOLE(f_sz); k_sr += SD_BOOLE(f_sr);
             }
 #undef SD_BOOLE
-            acc.i0 += v.rho * (dmmr + dmmz);                        // surfa.f:1126-1128
-            acc.i1 += l2m * dmmr + xmu * dmmz;
-            acc.i2 += xmu * dzsr - xlamb * drsz;
+            // the sublayer's contributions in fp32 as in the reference (surfa.f:1126-1128); only the
+            // running sums are fp64 (fp64 arithmetic runs at half rate)
+            acc.i0 += (double)(v.rho * (dmmr + dmmz));
+            acc.i1 += (double)(l2m * dmmr + xmu * dmmz);
+            acc.i2 += (double)(xmu * dzsr - xlamb * drsz);
         }
         if (kern)
             kern_add_rayleigh(ko, jl, chain_of(raw, lnT, jl == n - 1), v, xlamb, xmu, c, wvno, wvnosq, omegsq,
