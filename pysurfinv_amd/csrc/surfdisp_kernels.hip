@@ -569,8 +569,10 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
             // exact fp32 grid of the reference: c2 = c1 + dc repeatedly (calcul.f:157,161)
             const int nadd = (fastok && coarse) ? FSTRIDE * (js + 1) : (first ? js : js + 1);
             cj = p0c;
-            if (fastok) { for (int i = 0; i < nadd; ++i) cj = cj + DC; }
-            else {
+            if (fastok) {
+#pragma unroll
+                for (int i = 0; i < FSTRIDE * G; ++i) if (i < nadd) cj = cj + DC;
+            } else {
 #pragma unroll
                 for (int i = 0; i < G; ++i) if (i < nadd) cj = cj + DC;
             }
