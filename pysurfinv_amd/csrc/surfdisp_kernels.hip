@@ -947,26 +947,30 @@ SD_HD __forceinline__ RProp make_prop(const RCoef &q)
     const double k4 = t6 * w1 * wh * wh;
     const M2x2 m1 = {(double)q.a31, (double)q.a34, (double)q.a21, (double)q.a24};
     const M2x2 m2 = {(double)q.a13, (double)q.a12, (double)q.a43, (double)q.a42};
-    // one block of P at a time: the products of a block die before the next one starts (register
-    // pressure: this kernel sits at the 168-VGPR boundary of three wavefronts per SIMD)
+    // One block of P at a time (register pressure: this kernel sits at the 168-VGPR boundary of three
+    // wavefronts per SIMD).  N^2 of a 2x2 matrix is tr(N) N - det(N) I (Cayley-Hamilton), so
+    //   I + k2 N + k4 N^2 = (1 - k4 det) I + (k2 + k4 tr) N      and      k1 M + k3 N M = (k1 I + k3 N) M
+    // need no explicit N^2 and N M products (fp64 runs at half rate here).
     RProp P;
+    auto diag_block = [&](const M2x2 &nn) -> M2x2 {
+        const double tr = nn.a + nn.d;
+        const double det = fma(nn.a, nn.d, -(nn.b * nn.c));
+        const double al = fma(k4, tr, k2), be = fma(-k4, det, 1.0);
+        return M2x2{fma(al, nn.a, be), al * nn.b, al * nn.c, fma(al, nn.d, be)};
+    };
+    auto off_block = [&](const M2x2 &nn, const M2x2 &m) -> M2x2 {
+        const M2x2 q = {fma(k3, nn.a, k1), k3 * nn.b, k3 * nn.c, fma(k3, nn.d, k1)};
+        return mm(q, m);
+    };
     {
         const M2x2 n1 = mm(m1, m2);
-        {
-            const M2x2 n1s = mm(n1, n1);
-            P.p11 = {1.0 + fma(k2, n1.a, k4 * n1s.a), fma(k2, n1.b, k4 * n1s.b), fma(k2, n1.c, k4 * n1s.c), 1.0 + fma(k2, n1.d, k4 * n1s.d)};
-        }
-        const M2x2 n1m1 = mm(n1, m1);
-        P.p12 = {fma(k1, m1.a, k3 * n1m1.a), fma(k1, m1.b, k3 * n1m1.b), fma(k1, m1.c, k3 * n1m1.c), fma(k1, m1.d, k3 * n1m1.d)};
+        P.p11 = diag_block(n1);
+        P.p12 = off_block(n1, m1);
     }
     {
         const M2x2 n2 = mm(m2, m1);
-        {
-            const M2x2 n2s = mm(n2, n2);
-            P.p22 = {1.0 + fma(k2, n2.a, k4 * n2s.a), fma(k2, n2.b, k4 * n2s.b), fma(k2, n2.c, k4 * n2s.c), 1.0 + fma(k2, n2.d, k4 * n2s.d)};
-        }
-        const M2x2 n2m2 = mm(n2, m2);
-        P.p21 = {fma(k1, m2.a, k3 * n2m2.a), fma(k1, m2.b, k3 * n2m2.b), fma(k1, m2.c, k3 * n2m2.c), fma(k1, m2.d, k3 * n2m2.d)};
+        P.p22 = diag_block(n2);
+        P.p21 = off_block(n2, m2);
     }
     return P;
 }
