@@ -60,7 +60,7 @@ extern "C" {
                                      * of the secular function), (c) when three consecutive coarse values have
                                      * the same sign, the same layer dropping and a second difference below
                                      * twice the smaller end value.  Teams of 16+ lanes always scan exactly.
-                                     * 4.1e9 phase velocities of random stacks (rough, water-covered, thick)
+                                     * 1.5e10 phase velocities of random stacks (rough, water-covered, thick)
                                      * came out bit-identical in both modes (scripts/soak_scan.py); the flag
                                      * is there for callers who want the reference's evaluation sequence. */
 #define SURFDISP_PHASE_ONLY    0x10 /* OR into `kind` of the batched entries: phase velocities only
