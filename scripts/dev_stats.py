@@ -4,7 +4,7 @@
 pysurfinv_amd/lib/libsurfdisp_stats.so; not part of the product build.  r01g, bench workload:
   team 2: scan 19.2 passes, refine 1.28, ellipticity 1.00 per period (43 evaluations; reference 52)
   team 4: scan 10.4, refine 1.07, ellipticity 0.05 (rides in the next scan pass)   (48 evaluations)
-  default (certified coarse-to-fine) scan: team 2 scan 9.5 passes (5.2 coarse), team 4 scan 6.3 (3.4 coarse); a coarse pass
+  default (certified coarse-to-fine) scan, r01j: team 2 scan 9.1 passes (4.6 coarse), team 4 scan 5.8 (2.8 coarse); a coarse pass
   ends on the true sign change (1.0 per period), on the curvature test just before it (0.8) or on a change of the
   layer dropping (0.06); the figures above are SURFDISP_EXACTSCAN."""
 import ctypes, os, sys
