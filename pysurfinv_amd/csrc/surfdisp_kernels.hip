@@ -527,10 +527,23 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
     auto build = [&](int nflat) {
         const float lnT = logf(1.0f / T);                      // alog(t_base/t1), calcul.f:122
         for (int i = j; i < nflat; i += G) {
-            const LayerV v = layer_at(mdl, fs, (size_t)i * B + b, lnT, i == nflat - 1);
-            W_IR(i) = 1.0f / v.rho; W_B(i) = v.b; W_R(i) = v.rho; W_D(i) = v.d;
-            W_IA2(i) = 1.0f / (v.a * v.a);
-            W_IB2(i) = (v.b > 0.0f) ? 1.0f / (v.b * v.b) : 0.0f;
+            // only the fields this layer's role needs (regular: dif, qqq, dflat; half space: hsf, hsr);
+            // this block runs whenever ANY team of the wavefront changes period, i.e. almost every
+            // pass and with one or two teams active, so its loads and divisions are worth counting
+            const bool hs = (i == nflat - 1);
+            const size_t o = (size_t)i * B + b;
+            LayerRaw r;
+            r.a_ref = mdl[F_VP * fs + o]; r.b_ref = mdl[F_VS * fs + o]; r.rho_ref = mdl[F_RHO * fs + o];
+            r.qs = mdl[F_QS * fs + o];
+            r.dif = hs ? 0.0f : mdl[F_DIF * fs + o]; r.qqq = hs ? 0.0f : mdl[F_QQQ * fs + o];
+            r.dfl = hs ? 0.0f : mdl[F_DFL * fs + o];
+            r.hsf = hs ? mdl[F_HSF * fs + o] : 0.0f; r.hsr = hs ? mdl[F_HSR * fs + o] : 0.0f;
+            const LayerV v = layer_derive(r, lnT, hs);
+            // the reciprocals are this kernel's own helper values (not the reference's): v_rcp + one Newton
+            // step (<= 1 ulp) instead of three IEEE divisions
+            W_IR(i) = rcp_nr(v.rho); W_B(i) = v.b; W_R(i) = v.rho; W_D(i) = v.d;
+            W_IA2(i) = rcp_nr(v.a * v.a);
+            W_IB2(i) = (v.b > 0.0f) ? rcp_nr(v.b * v.b) : 0.0f;
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
