@@ -434,3 +434,18 @@ def test_default_scan_random_stacks_and_independent_mode(hip):
     c0, u0, s0 = hip.forward_batch(m, per, 2, independent=True, exact_scan=True)
     c1, u1, s1 = hip.forward_batch(m, per, 2, independent=True)
     assert np.array_equal(c0, c1) and np.array_equal(s0, s1)
+
+
+def test_pipelined_hint_changes_only_the_launch(hip, ref_cases):
+    """SURFDISP_PIPELINED picks the team size for two batches in flight; the results stay within the parity
+    band of every team size and the zero pattern is the same."""
+    import torch
+    from pysurfinv_amd import forward
+    d = ref_cases["synth_L10_R"]
+    model = torch.from_numpy(np.ascontiguousarray(np.repeat(d["model"], 512, axis=0))).cuda()
+    per = torch.from_numpy(d["periods"]).cuda()
+    plan = forward.BatchPlan(model.shape[0], model.shape[2], per.numel())
+    c0, u0, s0 = (t.clone() for t in plan.run(model, per, kind=2))
+    c1, u1, s1 = plan.run(model, per, kind=2, pipelined=True)
+    assert torch.equal(s0, s1) and torch.equal(c0 > 0, c1 > 0)
+    assert float((c1 / c0 - 1).abs().max()) < 4e-6 and float((u1 / u0 - 1).abs().max()) < 1e-5
