@@ -47,6 +47,9 @@ typedef struct {
     double yz1[NKN][5], yz2[NKN][5], yz3[NKN][5], yz4[NKN][5];
     /* counters for the work model (not in the reference) */
     long n_delta;
+    /* developer trace of the scan of one period (surfdisp_oracle_scan_trace; not in the reference) */
+    int tr_k, tr_cap, tr_n, tr_extra;
+    float *tr_c, *tr_d; int *tr_mm;
 } ctx_t;
 
 static inline float sgn1(float x) { return copysignf(1.0f, x); } /* SIGN(1.,x) */
@@ -783,7 +786,7 @@ static int forward_ctx(ctx_t *s, int nlay, int kind,
     int status = SURFDISP_ORACLE_OK;
     /* a new process sees zeroed COMMON blocks */
     memset(s->a, 0, 5 * NSZ * sizeof(float));
-    s->n_delta = 0;
+    s->n_delta = 0; s->tr_n = 0;
     s->n = nlay; s->kind = kind;
     for (int i = 0; i < nlay; ++i) {                      /* fast_surf.f:89-99 */
         s->a_ref[i] = vp[i]; s->b_ref[i] = vs[i]; s->rho_ref[i] = rho[i];
@@ -811,12 +814,24 @@ static int forward_ctx(ctx_t *s, int nlay, int kind,
         if (k > 0) c1 = 0.90f * c[k - 1];
         s->idrop = 0;
         float del1 = dltar(s, c1, t1, ifunc);
+        const int tracing = (s->tr_c != NULL) && (s->tr_k == k);
+        if (tracing && s->tr_n < s->tr_cap) { s->tr_c[s->tr_n] = c1; s->tr_d[s->tr_n] = del1; s->tr_mm[s->tr_n++] = s->mmax; }
         float c2, del2;
         int found = 0, failed = 0;
         for (;;) {
             c2 = c1 + dc;
             s->idrop = 0;
             del2 = dltar(s, c2, t1, ifunc);
+            if (tracing && s->tr_n < s->tr_cap) { s->tr_c[s->tr_n] = c2; s->tr_d[s->tr_n] = del2; s->tr_mm[s->tr_n++] = s->mmax; }
+            if (tracing && sgn1(del1) != sgn1(del2)) {          /* keep scanning tr_extra points past the bracket */
+                float cx = c2;
+                for (int e = 0; e < s->tr_extra && s->tr_n < s->tr_cap; ++e) {
+                    cx = cx + dc; s->idrop = 0;
+                    const float dx = dltar(s, cx, t1, ifunc);
+                    s->tr_c[s->tr_n] = cx; s->tr_d[s->tr_n] = dx; s->tr_mm[s->tr_n++] = s->mmax;
+                }
+                return SURFDISP_ORACLE_OK;
+            }
             if (sgn1(del1) != sgn1(del2)) { found = 1; break; }
             c1 = c2; del1 = del2;
             if (c1 - 0.8f * s->b[0] < 0.0f) { failed = 1; break; }
@@ -870,10 +885,29 @@ int surfdisp_oracle_forward(int nlay, int kind,
 {
     ctx_t *s = (ctx_t *)malloc(sizeof(ctx_t));
     if (!s) return SURFDISP_ORACLE_EINVAL;
+    s->tr_c = NULL;
     int st = forward_ctx(s, nlay, kind, vp, vs, rho, h, qsinv, per, nper, c_out, u_out,
                          nsolved, n_delta_out, NULL);
     free(s);
     return st;
+}
+
+/* developer aid: the secular-function values the scan of period k evaluates (grid point, value, effective half
+ * space), continued `extra` grid points past the first sign change; returns the number of points written */
+int surfdisp_oracle_scan_trace(int nlay, int kind,
+                               const float *vp, const float *vs, const float *rho,
+                               const float *h, const float *qsinv,
+                               const float *per, int nper, int k, int extra,
+                               float *c_tr, float *d_tr, int *mm_tr, int cap)
+{
+    ctx_t *s = (ctx_t *)calloc(1, sizeof(ctx_t));
+    if (!s) return 0;
+    float cbuf[SURFDISP_NPER_MAX], ubuf[SURFDISP_NPER_MAX];
+    s->tr_k = k; s->tr_cap = cap; s->tr_extra = extra; s->tr_c = c_tr; s->tr_d = d_tr; s->tr_mm = mm_tr;
+    forward_ctx(s, nlay, kind, vp, vs, rho, h, qsinv, per, nper, cbuf, ubuf, NULL, NULL, NULL);
+    const int n = s->tr_n;
+    free(s);
+    return n;
 }
 
 /* debug variant: also returns the Rayleigh ellipticity ratio(k) of calcul.f:195 */
@@ -885,6 +919,7 @@ int surfdisp_oracle_forward_dbg(int nlay, int kind,
 {
     ctx_t *s = (ctx_t *)malloc(sizeof(ctx_t));
     if (!s) return SURFDISP_ORACLE_EINVAL;
+    s->tr_c = NULL;
     int st = forward_ctx(s, nlay, kind, vp, vs, rho, h, qsinv, per, nper, c_out, u_out,
                          NULL, NULL, ratio_out);
     free(s);
@@ -922,6 +957,7 @@ int surfdisp_oracle_forward_batch(int B, int Lmax, const int *nlay, const float 
 #endif
     {
         ctx_t *s = (ctx_t *)malloc(sizeof(ctx_t));
+        if (s) s->tr_c = NULL;
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 16)
 #endif

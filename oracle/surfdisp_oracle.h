@@ -26,6 +26,13 @@ int surfdisp_oracle_forward(int nlay, int kind,
                             const float *per, int nper,
                             float *c_out, float *u_out, int *nsolved, long *n_delta);
 
+/* developer aid: secular-function values of the scan of period k (see the .c file) */
+int surfdisp_oracle_scan_trace(int nlay, int kind,
+                               const float *vp, const float *vs, const float *rho,
+                               const float *h, const float *qsinv,
+                               const float *per, int nper, int k, int extra,
+                               float *c_tr, float *d_tr, int *mm_tr, int cap);
+
 int surfdisp_oracle_forward_dbg(int nlay, int kind,
                                 const float *vp, const float *vs, const float *rho,
                                 const float *h, const float *qsinv,

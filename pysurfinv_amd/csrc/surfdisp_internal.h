@@ -33,6 +33,7 @@ struct PhaseArgs {
     int fast;             // certified coarse-to-fine scan (the default; 0 with SURFDISP_EXACTSCAN)
     const float *fsafe;   // [B], see PrepArgs
     int overlap;          // second LDS slot: the ellipticity passes ride in the next period's first scan pass
+    float phimax;         // certified scan: largest vertical-phase increment (rad) of an interval that may be skipped
 };
 
 struct GroupArgs {

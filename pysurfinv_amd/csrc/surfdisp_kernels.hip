@@ -229,8 +229,12 @@ __device__ __forceinline__ void sincos_cw(float x, float *sn, float *cs)
 // c-independent 1/a^2, 1/b^2 taken from LDS.
 __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap, const int S,
                                                 const int mmax, const float c, const float T,
-                                                const int start)
+                                                const int start, float &phi)
 {
+    // phi: vertical phase sum_i k d_i sqrt(c^2/v_i^2 - 1) over the layers (and wave types) that are oscillatory
+    // at c -- the WKB mode counter the certified scan bounds between two coarse points (free: pm and qm are
+    // the recursion's own arguments)
+    phi = 0.0f;
     const float wvno = 6.28318531f / (c * T);
     const float csq = c * c;
     const float icsq = 1.0f / csq;
@@ -260,6 +264,7 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             } else {
                 float sn, cs; sincos_cw(pm, &sn, &cs);
                 sinpr = sn / ra; cosp = cs;
+                phi += pm;
             }
             // only a11 and a21 are non-zero (surfa.f:236-250)
             const float n1 = cosp * b1;
@@ -287,12 +292,14 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         } else {                                           // oscillatory P, surfa.f:271-273
             float sn, cs; sincos_cw(pm, &sn, &cs);
             rsinp = ra * sn; sinpr = sn * rcp_nr(ra); cosp = cs;
+            phi += pm;
         }
         if (fabsf(rb) < ACCUR) {
             rsinq = 0.0f; sinqr = wd; cosq = 1.0f;
         } else if (rb > 0.0f) {
             float sn, cs; sincos_cw(qm, &sn, &cs);
             rsinq = rb * sn; sinqr = sn * rcp_nr(rb); cosq = cs;
+            phi += qm;
         } else {
             float sh, ch; sinhcosh_sp(qm, &sh, &ch);
             rsinq = -rb * sh;
@@ -379,8 +386,9 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
 
 // Love: Thomson-Haskell 2-vector from the half space up, surfa.f:143-179.
 __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, const int S,
-                                            const int mmax, const float c, const float T)
+                                            const int mmax, const float c, const float T, float &phi)
 {
+    phi = 0.0f;                                            // see delta_rayleigh
     const float wvno = 6.2831853f / (c * T);
     const float csq = c * c;
     const int mh = mmax - 1;
@@ -410,6 +418,7 @@ __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, con
         } else {
             float sn, cs; sincos_cw(q, &sn, &cs);
             yv = sn * rcp_nr(rb); z = rb * sn; cosq = cs;
+            phi -= q;
         }
         const float eut = cosq * ut - yv * tt * ih;
         const float ett = h * z * ut + cosq * tt;
@@ -514,7 +523,9 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
     const float fsafe = (fastok && team_valid) ? A.fsafe[b] : 1.0e30f;
     bool coarse = false;               // this pass scans on the coarse grid
     int fine_left = 1;                 // fine points still to scan before going (back) to coarse
-    float q0d = 0.0f; int q0mm = 0; bool q0ok = false;   // the coarse point before p0 (for lane 0)
+    // q0ok: the coarse point before p0 (for lane 0); !q0ok (first coarse pass after fine ones): the fine point p0 - dc
+    float q0c = 0.0f, q0d = 0.0f; int q0mm = 0; bool q0ok = false;
+    float p0phi = 0.0f;                // vertical phase (delta_rayleigh) at p0c, valid whenever coarse is set
     // pending ellipticity of the previous period (OVERLAP): evaluated by lanes 0-1 of the first
     // scan pass of the next period instead of costing a pass of its own
     bool ell_pend = false;
@@ -614,10 +625,10 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
             start = (G == 1) ? 2 + sub : 2 + j;
             eval = (G == 1) || (j < 2);
         }
-        float val = 0.0f;
+        float val = 0.0f, phj = 0.0f;
         if (eval) {
-            if (KIND == 2) val = delta_rayleigh(wl, Lcap, S, mmj, cj, Tl, start);
-            else           val = delta_love(wl, Lcap, S, mmj, cj, Tl);
+            if (KIND == 2) val = delta_rayleigh(wl, Lcap, S, mmj, cj, Tl, start, phj);
+            else           val = delta_love(wl, Lcap, S, mmj, cj, Tl, phj);
         }
         // ---------------------------------------------------------------- team-level decisions
         const int lm1 = (lane + 63) & 63;
@@ -638,25 +649,60 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         // half space at three consecutive coarse points around it, and bends so little over them
         // (second difference < 2 x the smaller end value; a dip to zero inside would need ~8 x) that
         // no pair of roots can hide in it.  Anything else is rescanned point by point.
-        bool uncert = false;
+        bool uncert = false, back0 = false;
         if (fastok) {
         const int ln1 = (lane + 1) & 63, lm2 = (lane + 62) & 63;
         const float nx_d = __shfl(val, ln1), sp_d = __shfl(val, lm2);
         const int nx_mm = __shfl(mmj, ln1), sp_mm = __shfl(mmj, lm2);
+        const float sphi = __shfl(phj, lm1), nphi = __shfl(phj, ln1);
+        // ln(p n / m^2) < 1 for three same-sign values: the second difference of ln|Delta| at the middle point.
+        // A pair of roots between two coarse points lifts it to >= 2.2 at one of them whatever exponential
+        // envelope multiplies the function (soft layers: e^{k d} factors change Delta by orders of magnitude
+        // per coarse step and hide a sign-changing hump from the linear test below)
+        auto logsd_ok = [](float p, float m, float n) {
+            const float rm = __builtin_amdgcn_rcpf(m);
+            const float a = p * rm, b = n * rm;
+            return (a > 0.0f) && (b > 0.0f) && (a * b < 2.7182818f);
+        };
         if (coarse && st == ST_SCAN) {
             const bool has_next = (j < G - 1);
             const bool has_pp = (j >= 1) || q0ok;
             const float pp_d = (j >= 2) ? sp_d : ((j == 1) ? p0d : q0d);
             const int pp_mm = (j >= 2) ? sp_mm : ((j == 1) ? p0mm : q0mm);
             const float lim = 2.0f * fminf(fabsf(pd), fabsf(val));
+            // right end: with the next point (a last lane's right end is looked at by lane 0 of the next pass, back0
+            // below).  A next point of the other sign means a root in the NEXT interval; two more in this one
+            // would be three modes within two intervals, which the phase rule excludes.
+            const bool nx_same = (negnan(nx_d) == negnan(val));
             const bool okf = !has_next || ((pmm == mmj) && (mmj == nx_mm) && fin(nx_d) &&
-                                           (fabsf(pd - 2.0f * val + nx_d) < lim));
+                                           (fabsf(pd - 2.0f * val + nx_d) < lim) &&
+                                           (nx_same ? logsd_ok(pd, val, nx_d) : (fabsf(nphi - phj) < A.phimax)));
+            // left end: with the coarse point before ...
+            const bool oklog_b = has_pp && logsd_ok(pp_d, pd, val);
             const bool okb = !has_pp || ((pp_mm == pmm) && (pmm == mmj) && fin(pp_d) &&
-                                         (fabsf(pp_d - 2.0f * pd + val) < lim));
+                                         (fabsf(pp_d - 2.0f * pd + val) < lim) && oklog_b);
+            // ... or, in the first coarse pass after fine ones, with the fine point before p0: the slope of
+            // ln|Delta| over the last fine step against the slope over this interval (a pair close behind p0
+            // bends it by 1.2-2.3 per fine step; 0.5 is allowed)
+            bool oke = true;
+            if (j == 0 && !q0ok) {
+                const float rf = pd * __builtin_amdgcn_rcpf(q0d), rc = val * __builtin_amdgcn_rcpf(pd);
+                const float rf2 = rf * rf;
+                const float x = rc * __builtin_amdgcn_rcpf(rf2 * rf2);
+                oke = (q0mm == pmm) && (pmm == mmj) && (rf > 0.0f) && (rc > 0.0f) && (x > 0.135f) && (x < 7.39f);
+            }
             // the secular function is analytic in c except at the half-space velocity (its closure is
             // linear in sqrt|c^2/b^2 - 1|): within two coarse steps of that branch point nothing is skipped
             const bool near_hs = !(cj < W_B(mmj - 1) - 2.0f * (float)FSTRIDE * DC);
-            uncert = near_hs || !((has_next || has_pp) && okf && okb && fin(pd) && fin(val));
+            // ... and the interval must be too short for two modes: consecutive modes are ~pi apart in the
+            // vertical phase summed over the oscillatory layers, however the stack is built (thick or slow
+            // layers, short periods); the interval may add at most A.phimax (pi/2 by default) to it
+            const float pphi = (j == 0) ? p0phi : sphi;
+            const bool okphi = fabsf(phj - pphi) < A.phimax;
+            uncert = near_hs || !(okf && okb && oke && okphi && fin(pd) && fin(val));
+            // lane 0 also holds the right end of the previous pass's last interval (q0, p0): if that fails the
+            // rescan starts at q0
+            back0 = (j == 0) && q0ok && (cross ? !okphi : !oklog_b);
         }
         }
         const bool ev = searching && (cross || guard || uncert);
@@ -669,8 +715,10 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         const int e_pmm = __shfl(pmm, src);
         const int l_mm = __shfl(mmj, tbase + G - 1);
         const int e_cross = __shfl((int)cross, src);
+        const int t_back0 = __shfl((int)back0, tbase);
         const int lastl = tbase + G - 1;
         const float l_c = __shfl(cj, lastl), l_d = __shfl(val, lastl);
+        const float l_phi = fastok ? __shfl(phj, lastl) : 0.0f;
         const float v0 = __shfl(val, tbase), v1 = __shfl(val, (G > 1) ? tbase + 1 : tbase);
         const int nxt = (src < lastl) ? src + 1 : lastl;       // right neighbour of the crossing lane
         const float e_nc = __shfl(cj, nxt), e_nd = __shfl(val, nxt);
@@ -701,13 +749,15 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
             ++passes;
             if (fl >= 0) {                                     // rescan this interval point by point
                 p0c = e_pc; p0d = e_pd; p0mm = e_pmm;
+                const bool e_back = (fl == tbase) && (t_back0 != 0);
+                if (e_back) { p0c = q0c; p0d = q0d; p0mm = q0mm; }
                 // an interval that merely failed the certificate usually sits just below the root (the
                 // smaller end value is what the curvature is compared with): stay on the fine grid for
                 // the next interval too instead of spending a coarse pass on finding the sign change there
-                coarse = false; fine_left = e_cross ? FSTRIDE : 2 * FSTRIDE; q0ok = false;
+                coarse = false; fine_left = (e_cross && !e_back) ? FSTRIDE : 2 * FSTRIDE; q0ok = false;
             } else {
-                q0d = pl_d; q0mm = pl_mm; q0ok = true;
-                p0c = l_c; p0d = l_d; p0mm = l_mm;
+                q0c = pl_c; q0d = pl_d; q0mm = pl_mm; q0ok = true;
+                p0c = l_c; p0d = l_d; p0mm = l_mm; p0phi = l_phi;
             }
         } else if (st == ST_SCAN) {
             ++passes;
@@ -723,6 +773,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
                 failed = true;                                 // label 250
             } else {
                 p0c = l_c; p0d = l_d; p0mm = l_mm; first = false;
+                if (fastok) { p0phi = l_phi; q0d = pl_d; q0mm = pl_mm; }    // pl: the fine point p0 - dc
                 if (passes > 100000) failed = true;            // cannot happen: c grows by dc/pass
                 if (fastok) {
                     fine_left -= had_ell ? G - 2 : G;

@@ -14,16 +14,27 @@ T_END = time.time() + float(os.environ.get("SOAK_SECONDS", "120"))
 MONO = os.environ.get("SOAK_MONO", "1") == "1"
 T_LAST = time.time()
 nst = nval = ndif = npat = ncase = 0
+byfam = {}
 worst = []
+saved = []
 while time.time() < T_END:
+    plo, phi = 3.0, 150.0; fam = 'synth'
     Ln = int(rng.integers(2, 48)); B = 4096; kind = int(rng.integers(1, 3))
     noise = float(rng.choice([0.02, 0.05, 0.1, 0.2])); tt = float(rng.choice([30., 60., 120., 200., 400.]))
     mono = True if MONO else bool(rng.random() < 0.5)
     m = synth.synth_models(B, Ln, seed=int(rng.integers(1 << 30)), noise=noise, monotone=mono, total_thickness=tt)
     if rng.random() < 0.2 and Ln >= 4:
-        m[:, 1, 0] = 0.0; m[:, 0, 0] = 1.475; m[:, 2, 0] = 1.027; m[:, 4, 0] = 1e-4; m[:, 3, 0] = rng.uniform(0.3, 4.0, B)
+        m[:, 1, 0] = 0.0; m[:, 0, 0] = 1.475; m[:, 2, 0] = 1.027; m[:, 4, 0] = 1e-4; m[:, 3, 0] = rng.uniform(0.3, 4.0, B); fam = 'water'
+    elif rng.random() < 0.3 and Ln >= 4:
+        # soft sediments over rock: strong contrast, fundamental and first overtone nearly touch (osculation)
+        ns = int(rng.integers(1, min(4, Ln - 1) + 1))
+        vs = np.sort(rng.uniform(0.2, 1.4, (B, ns)), axis=1)
+        m[:, 1, :ns] = vs; m[:, 0, :ns] = np.minimum(vs * rng.uniform(1.8, 3.5, (B, 1)), m[:, 0, ns:ns + 1])
+        m[:, 0, :ns] = np.sort(m[:, 0, :ns], axis=1)
+        m[:, 2, :ns] = rng.uniform(1.8, 2.3, (B, ns)); m[:, 3, :ns] = rng.uniform(0.2, 3.0, (B, ns))
+        plo, phi = 0.3, 30.0; fam = 'sediment'
     P = int(rng.integers(1, 40))
-    per = np.sort(rng.uniform(3.0, 150.0, P)).astype(np.float32)
+    per = np.sort(rng.uniform(plo, phi, P)).astype(np.float32)
     team = int(rng.choice([2, 4, 8])); L.surfdisp_set_team(team)
     md = torch.from_numpy(m).cuda(); pd = torch.from_numpy(per).cuda()
     plan = forward.BatchPlan(B, Ln, P)
@@ -32,13 +43,23 @@ while time.time() < T_END:
     d = (c0 != c1)
     nd = int(d.sum()); ndif += nd; nval += c0.numel(); nst += B; ncase += 1
     npat += int(((c0 > 0) != (c1 > 0)).any(dim=1).sum())
+    f = byfam.setdefault((fam, kind), [0, 0, 0]); f[0] += c0.numel(); f[1] += nd; f[2] += int(((c0 > 0) != (c1 > 0)).sum())
     if nd:
         worst.append((nd, Ln, kind, noise, tt, P, team, float((c0 - c1).abs().max())))
+        if len(saved) < 40:
+            rows = torch.nonzero(d.any(dim=1)).flatten()[:4].cpu().numpy()
+            for r in rows:
+                saved.append(dict(model=m[r], per=per, kind=kind, team=team, c_exact=c0[r].cpu().numpy(), c_default=c1[r].cpu().numpy()))
     if time.time() - T_LAST > 45:
         T_LAST = time.time()
         print(f"  ... {ncase} cases, {nst} stacks, {nval} phase velocities, {ndif} differ, {npat} stacks with another zero pattern", flush=True)
 L.surfdisp_set_team(0)
+if saved:
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    np.save(os.path.join(ROOT, 'gpurun_out', 'scanfail.npy'), np.array(saved, dtype=object), allow_pickle=True)
 print(f"scan soak, default vs exact (monotone only: {MONO}): {ncase} cases, {nst} stacks, {nval} phase velocities; {ndif} differ ({ndif / max(nval, 1):.2e}); "
       f"{npat} stacks with a different zero pattern")
+for k, v in sorted(byfam.items()):
+    print(f"   family {k[0]:9s} kind {k[1]}: {v[0]} values, {v[1]} differ, {v[2]} of them zero/non-zero")
 for w in sorted(worst, reverse=True)[:15]:
     print("   differ %d: L=%d kind=%d noise=%.2f thick=%.0f P=%d team=%d max|dc|=%.2e" % w)
