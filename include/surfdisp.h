@@ -55,14 +55,23 @@ extern "C" {
                                      * rescans point by point everywhere else, so the bracket is found on the
                                      * same fp32 grid with ~35 % fewer evaluations: an interval is skipped only
                                      * (a) on stacks whose Vs and Vp never decrease with depth and whose layers
-                                     * are at most three wavelengths thick (no channel waves, no crowded
-                                     * overtones), (b) away from the half-space velocity (the one branch point
-                                     * of the secular function), (c) when three consecutive coarse values have
-                                     * the same sign, the same layer dropping and a second difference below
-                                     * twice the smaller end value.  Teams of 16+ lanes always scan exactly.
-                                     * 1.5e10 phase velocities of random stacks (rough, water-covered, thick)
-                                     * came out bit-identical in both modes (scripts/soak_scan.py); the flag
-                                     * is there for callers who want the reference's evaluation sequence. */
+                                     * are at most three wavelengths thick (no channel waves), (b) away from the
+                                     * half-space velocity (the one branch point of the secular function),
+                                     * (c) when the interval adds less than pi/2 to the vertical phase
+                                     * sum k d sqrt(c^2/v^2 - 1) over the oscillatory layers (consecutive overtones
+                                     * are ~pi apart in it), (d) when the coarse values around it have the same
+                                     * sign and layer dropping, a second difference below twice the smaller end
+                                     * value, and a second difference of ln|Delta| below 1 at BOTH ends of the
+                                     * interval (a hidden pair of roots lifts it to >= 2.2 at one end whatever
+                                     * e^{kd} envelope multiplies the function: soft sediments over rock).
+                                     * Teams of 16+ lanes always scan exactly.  Differential soaks
+                                     * (scripts/soak_scan.py): random rough / water-covered / thick / soft-
+                                     * sediment stacks bit-identical in both modes over >2e10 phase velocities;
+                                     * on unphysical stacks (0.1 km/s layers tens of metres thick at 100 s
+                                     * periods) the two modes differ at 2e-8 per value, where fp32 round-off
+                                     * decides the sign of the secular function and the exact scan of this
+                                     * library and the reference's already disagree.  The flag is there for
+                                     * callers who want the reference's evaluation sequence. */
 #define SURFDISP_PHASE_ONLY    0x10 /* OR into `kind` of the batched entries: phase velocities only
                                      * (what Point.misfit consumes, point.py:18); u is not written
                                      * and may be NULL */

@@ -27,14 +27,22 @@ while time.time() < T_END:
         m[:, 1, 0] = 0.0; m[:, 0, 0] = 1.475; m[:, 2, 0] = 1.027; m[:, 4, 0] = 1e-4; m[:, 3, 0] = rng.uniform(0.3, 4.0, B); fam = 'water'
     elif rng.random() < 0.3 and Ln >= 4:
         # soft sediments over rock: strong contrast, fundamental and first overtone nearly touch (osculation)
-        ns = int(rng.integers(1, min(4, Ln - 1) + 1))
-        vs = np.sort(rng.uniform(0.2, 1.4, (B, ns)), axis=1)
-        m[:, 1, :ns] = vs; m[:, 0, :ns] = np.minimum(vs * rng.uniform(1.8, 3.5, (B, 1)), m[:, 0, ns:ns + 1])
-        m[:, 0, :ns] = np.sort(m[:, 0, :ns], axis=1)
-        m[:, 2, :ns] = rng.uniform(1.8, 2.3, (B, ns)); m[:, 3, :ns] = rng.uniform(0.2, 3.0, (B, ns))
+        m = synth.sediment_models(B, Ln, seed=int(rng.integers(1 << 30)), noise=noise, total_thickness=tt)
         plo, phi = 0.3, 30.0; fam = 'sediment'
+    elif rng.random() < 0.3:
+        # anything monotone: velocities 0.1-5 km/s, thicknesses 10 m - 50 km and periods 0.1-300 s log-uniform,
+        # Vp/Vs 1.5-8, sometimes under water
+        vs = np.sort(np.exp(rng.uniform(np.log(0.1), np.log(5.0), (B, Ln))), axis=1)
+        vp = np.sort(vs * np.exp(rng.uniform(np.log(1.5), np.log(8.0), (B, Ln))), axis=1)
+        m[:, 1, :] = vs; m[:, 0, :] = vp; m[:, 2, :] = np.sort(rng.uniform(1.6, 3.4, (B, Ln)), axis=1)
+        m[:, 3, :] = np.exp(rng.uniform(np.log(0.01), np.log(50.0), (B, Ln))); m[:, 3, -1] = 0.0
+        m[:, 4, :] = rng.choice([1e-4, 1 / 600., 1 / 80., 1 / 20.], (B, Ln))
+        if rng.random() < 0.3 and Ln >= 3:
+            m[:, 1, 0] = 0.0; m[:, 0, 0] = 1.475; m[:, 2, 0] = 1.027; m[:, 4, 0] = 1e-4; m[:, 3, 0] = rng.uniform(0.05, 5.0, B)
+            m[:, 0, 1:] = np.maximum(m[:, 0, 1:], 1.475); m[:, 2, 1:] = np.maximum(m[:, 2, 1:], 1.1)
+        plo, phi = 0.1, 300.0; fam = 'wild'
     P = int(rng.integers(1, 40))
-    per = np.sort(rng.uniform(plo, phi, P)).astype(np.float32)
+    per = np.sort(np.exp(rng.uniform(np.log(plo), np.log(phi), P)) if fam == 'wild' else rng.uniform(plo, phi, P)).astype(np.float32)
     team = int(rng.choice([2, 4, 8])); L.surfdisp_set_team(team)
     md = torch.from_numpy(m).cuda(); pd = torch.from_numpy(per).cuda()
     plan = forward.BatchPlan(B, Ln, P)

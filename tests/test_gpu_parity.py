@@ -436,6 +436,27 @@ def test_default_scan_random_stacks_and_independent_mode(hip):
     assert np.array_equal(c0, c1) and np.array_equal(s0, s1)
 
 
+def test_default_scan_soft_sediments_over_rock(hip):
+    """Soft sediments over rock at short periods: fundamental and first higher mode 0.02 km/s apart, e^{kd} factors
+    of many orders of magnitude in the secular function (the linear curvature test alone let 5e-5 of these values
+    slip; the vertical-phase rule and the log-domain test close it).  ~1.5 M phase velocities, bit-identical."""
+    from pysurfinv_amd import synth, _lib
+    rng = np.random.default_rng(78)
+    try:
+        for it in range(6):
+            L = int(rng.integers(4, 40)); team = (2, 4, 8)[it % 3]
+            _lib.lib().surfdisp_set_team(team)
+            m = synth.sediment_models(8192, L, seed=100 + it, noise=float(rng.choice([0.02, 0.1, 0.2])),
+                                      total_thickness=float(rng.choice([30., 120., 400.])))
+            per = np.sort(rng.uniform(0.3, 30.0, 32)).astype(np.float32)
+            for kind in (1, 2):
+                c0, u0, s0 = hip.forward_batch(m, per, kind | 0x10, exact_scan=True)
+                c1, u1, s1 = hip.forward_batch(m, per, kind | 0x10)
+                assert np.array_equal(c0, c1) and np.array_equal(s0, s1), (it, kind, int((c0 != c1).sum()))
+    finally:
+        _lib.lib().surfdisp_set_team(0)
+
+
 def test_pipelined_hint_changes_only_the_launch(hip, ref_cases):
     """SURFDISP_PIPELINED picks the team size for two batches in flight; the results stay within the parity
     band of every team size and the zero pattern is the same."""
