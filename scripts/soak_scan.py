@@ -15,6 +15,17 @@ MONO = os.environ.get("SOAK_MONO", "1") == "1"
 T_LAST = time.time()
 nst = nval = ndif = npat = ncase = 0
 byfam = {}
+# realistic stacks: uniform prior draws of the continental and the thermal oceanic parametrisation (tests/golden)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from settings import CONT
+from settings_therm import HYBRID_STATIC
+from pysurfinv_amd.layers_batch import Model1DBatch
+from pysurfinv_amd.mcmc import MetropolisBatch
+PRIOR = {}
+for nm, st in (("prior_cont", CONT), ("prior_ocean", HYBRID_STATIC)):
+    mb = Model1DBatch(st, device="cuda:0")
+    PRIOR[nm] = (mb, MetropolisBatch(mb.spec, mb.to_model, np.array([10., 20.]), np.array([3.5, 3.6]), np.array([.01, .01]),
+                                     device="cuda:0", seed=int(os.environ.get("SOAK_SEED", "0"))))
 worst = []
 saved = []
 while time.time() < T_END:
@@ -41,13 +52,20 @@ while time.time() < T_END:
             m[:, 1, 0] = 0.0; m[:, 0, 0] = 1.475; m[:, 2, 0] = 1.027; m[:, 4, 0] = 1e-4; m[:, 3, 0] = rng.uniform(0.05, 5.0, B)
             m[:, 0, 1:] = np.maximum(m[:, 0, 1:], 1.475); m[:, 2, 1:] = np.maximum(m[:, 2, 1:], 1.1)
         plo, phi = 0.1, 300.0; fam = 'wild'
+    nl_t = None
+    if rng.random() < 0.15:
+        fam = str(rng.choice(list(PRIOR))); mb, mc = PRIOR[fam]
+        md_t, nl_t = mb.to_model(mc.reset(B)); md_t = md_t.contiguous()
+        m = md_t.cpu().numpy(); Ln = m.shape[2]
+        plo, phi = (5.0, 100.0) if fam == "prior_cont" else (4.0, 40.0)
     P = int(rng.integers(1, 40))
     per = np.sort(np.exp(rng.uniform(np.log(plo), np.log(phi), P)) if fam == 'wild' else rng.uniform(plo, phi, P)).astype(np.float32)
     team = int(rng.choice([2, 4, 8])); L.surfdisp_set_team(team)
     md = torch.from_numpy(m).cuda(); pd = torch.from_numpy(per).cuda()
+    kw = {} if nl_t is None else {'nlay': nl_t}
     plan = forward.BatchPlan(B, Ln, P)
-    c0, u0, s0 = plan.run(md, pd, kind=kind | 0x10, exact_scan=True); c0 = c0.clone(); s0 = s0.clone()
-    c1, u1, s1 = plan.run(md, pd, kind=kind | 0x10)
+    c0, u0, s0 = plan.run(md, pd, kind=kind | 0x10, exact_scan=True, **kw); c0 = c0.clone(); s0 = s0.clone()
+    c1, u1, s1 = plan.run(md, pd, kind=kind | 0x10, **kw)
     d = (c0 != c1)
     nd = int(d.sum()); ndif += nd; nval += c0.numel(); nst += B; ncase += 1
     npat += int(((c0 > 0) != (c1 > 0)).any(dim=1).sum())
