@@ -24,6 +24,10 @@ while time.time() < T_END:
         model[:, 3, 0] = rng.uniform(0.3, 4.0, B)
         model[:, 1, 1] = rng.uniform(0.6, 1.8, B); model[:, 0, 1] = 1.23 * model[:, 1, 1] + 1.28
         model[:, 3, 1] = rng.uniform(0.2, 2.0, B)
+    sed = os.environ.get("SOAK_FAMILY") == "sediment" and L >= 4 and rng.random() < 0.7
+    if sed:                                                 # soft sediments over rock (synth.sediment_models)
+        model = synth.sediment_models(B, L, seed=int(rng.integers(1 << 30)), noise=noise,
+                                      total_thickness=float(rng.choice([30., 60., 120., 200., 400.])))
     nlay = None
     if rng.random() < 0.3 and L > 3:
         nlay = rng.integers(2, L + 1, B).astype(np.int32)
@@ -31,6 +35,8 @@ while time.time() < T_END:
     per = np.sort(rng.uniform(3.0, 150.0, P)).astype(np.float32)
     if rng.random() < 0.5:
         per = np.linspace(rng.uniform(4, 12), rng.uniform(40, 120), P).astype(np.float32)
+    if sed:
+        per = np.sort(rng.uniform(0.3, 30.0, P)).astype(np.float32)
     team = int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64]))
     _lib.lib().surfdisp_set_team(team)
     c, u, st = forward.forward_batch(model, per, kind, nlay=nlay)
