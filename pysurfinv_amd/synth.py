@@ -32,19 +32,24 @@ def synth_models(B: int, L: int, seed: int = 0, noise: float = 0.03, monotone: b
     return np.stack([vp, vs, rho, h, 1.0 / qs], axis=1).astype(np.float32)
 
 
-def sediment_models(B: int, L: int, seed: int = 0, noise: float = 0.05, total_thickness: float = 120.0) -> np.ndarray:
+def sediment_models(B: int, L: int, seed: int = 0, noise: float = 0.05, total_thickness: float = 120.0,
+                    max_layers: int = 4, water: bool = False) -> np.ndarray:
     """Soft sediments (Vs 0.2-1.4 km/s, Vp/Vs 1.8-3.5, one to four layers of 0.2-3 km) over the monotone rock
     stack of ``synth_models``: fundamental and first higher Rayleigh mode come within 0.02 km/s of each other
     and the secular function carries e^{kd} factors of many orders of magnitude -- the hard case for the
     certified scan (tests/test_gpu_parity.py, scripts/soak_scan.py)."""
     rng = np.random.default_rng(seed)
     m = synth_models(B, L, seed=seed + 1, noise=noise, monotone=True, total_thickness=total_thickness)
-    ns = int(rng.integers(1, min(4, L - 1) + 1))
-    vs = np.sort(rng.uniform(0.2, 1.4, (B, ns)), axis=1)
+    ns = int(rng.integers(1, min(max_layers, L - 1) + 1))
+    vs = np.sort(rng.uniform(0.2, 1.4 if max_layers <= 4 else 3.0, (B, ns)), axis=1)
     m[:, 1, :ns] = vs
     m[:, 0, :ns] = np.sort(np.minimum(vs * rng.uniform(1.8, 3.5, (B, 1)), m[:, 0, ns:ns + 1]), axis=1)
     m[:, 2, :ns] = rng.uniform(1.8, 2.3, (B, ns))
-    m[:, 3, :ns] = rng.uniform(0.2, 3.0, (B, ns))
+    m[:, 3, :ns] = rng.uniform(0.2, 3.0, (B, ns)) * min(1.0, 4.0 / ns)
+    if water and L >= 3:                                   # ``max_layers`` > 4: a gradient of thinner layers up to 3 km/s
+        m[:, 1, 0] = 0.0; m[:, 0, 0] = 1.475; m[:, 2, 0] = 1.027; m[:, 4, 0] = 1e-4
+        m[:, 3, 0] = rng.uniform(0.05, 5.0, B)
+        m[:, 0, 1:] = np.maximum(m[:, 0, 1:], 1.48)
     return m
 
 

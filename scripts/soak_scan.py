@@ -38,7 +38,8 @@ while time.time() < T_END:
         m[:, 1, 0] = 0.0; m[:, 0, 0] = 1.475; m[:, 2, 0] = 1.027; m[:, 4, 0] = 1e-4; m[:, 3, 0] = rng.uniform(0.3, 4.0, B); fam = 'water'
     elif rng.random() < 0.3 and Ln >= 4:
         # soft sediments over rock: strong contrast, fundamental and first overtone nearly touch (osculation)
-        m = synth.sediment_models(B, Ln, seed=int(rng.integers(1 << 30)), noise=noise, total_thickness=tt)
+        m = synth.sediment_models(B, Ln, seed=int(rng.integers(1 << 30)), noise=noise, total_thickness=tt,
+                                  max_layers=int(rng.choice([4, 4, 12])), water=bool(rng.random() < 0.3))
         plo, phi = 0.3, 30.0; fam = 'sediment'
     elif rng.random() < 0.3:
         # anything monotone: velocities 0.1-5 km/s, thicknesses 10 m - 50 km and periods 0.1-300 s log-uniform,
