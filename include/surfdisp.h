@@ -66,9 +66,9 @@ extern "C" {
                                      * e^{kd} envelope multiplies the function: soft sediments over rock).
                                      * Teams of 16+ lanes always scan exactly.  Differential soaks
                                      * (scripts/soak_scan.py): random rough / water-covered / thick / soft-
-                                     * sediment stacks bit-identical in both modes over 2.7e10 phase velocities;
+                                     * sediment stacks bit-identical in both modes over 2.9e10 phase velocities;
                                      * on unphysical stacks (0.1 km/s layers tens of metres thick at 100 s
-                                     * periods) the two modes differ at 6e-9 per value, where fp32 round-off
+                                     * periods) the two modes differ at 1e-8 per value, where fp32 round-off
                                      * decides the sign of the secular function and the exact scan of this
                                      * library and the reference's already disagree.  The flag is there for
                                      * callers who want the reference's evaluation sequence. */

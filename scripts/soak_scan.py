@@ -64,6 +64,8 @@ while time.time() < T_END:
     team = int(rng.choice([2, 4, 8])); L.surfdisp_set_team(team)
     md = torch.from_numpy(m).cuda(); pd = torch.from_numpy(per).cuda()
     kw = {} if nl_t is None else {'nlay': nl_t}
+    indep = bool(rng.random() < 0.15)
+    if indep: kw['independent'] = True; fam = fam + '/indep'
     plan = forward.BatchPlan(B, Ln, P)
     c0, u0, s0 = plan.run(md, pd, kind=kind | 0x10, exact_scan=True, **kw); c0 = c0.clone(); s0 = s0.clone()
     c1, u1, s1 = plan.run(md, pd, kind=kind | 0x10, **kw)
