@@ -53,25 +53,26 @@ extern "C" {
                                      * (calcul.f:143-166).  By default the search steps over four grid points at
                                      * a time where that provably-in-practice cannot hide a pair of roots and
                                      * rescans point by point everywhere else, so the bracket is found on the
-                                     * same fp32 grid with ~35 % fewer evaluations: an interval is skipped only
+                                     * same fp32 grid with ~45 % fewer evaluations: an interval is skipped only
                                      * (a) on stacks whose Vs and Vp never decrease with depth and whose layers
                                      * are at most three wavelengths thick (no channel waves), (b) away from the
                                      * half-space velocity (the one branch point of the secular function),
-                                     * (c) when the interval adds less than pi/2 to the vertical phase
+                                     * (c) when the interval adds less than pi/4 to the vertical phase
                                      * sum k d sqrt(c^2/v^2 - 1) over the oscillatory layers (consecutive overtones
                                      * are ~pi apart in it), (d) when the coarse values around it have the same
-                                     * sign and layer dropping, a second difference below twice the smaller end
-                                     * value, and a second difference of ln|Delta| below 1 at BOTH ends of the
-                                     * interval (a hidden pair of roots lifts it to >= 2.2 at one end whatever
-                                     * e^{kd} envelope multiplies the function: soft sediments over rock).
+                                     * sign and layer dropping and the second difference of ln|Delta| is below 1
+                                     * at BOTH ends of the interval (a hidden pair of roots lifts it to >= 2.2 at
+                                     * one end whatever e^{kd} envelope multiplies the function).
                                      * Teams of 16+ lanes always scan exactly.  Differential soaks
                                      * (scripts/soak_scan.py): random rough / water-covered / thick / soft-
-                                     * sediment stacks bit-identical in both modes over 2.9e10 phase velocities;
-                                     * on unphysical stacks (0.1 km/s layers tens of metres thick at 100 s
-                                     * periods) the two modes differ at 1e-8 per value, where fp32 round-off
-                                     * decides the sign of the secular function and the exact scan of this
-                                     * library and the reference's already disagree.  The flag is there for
-                                     * callers who want the reference's evaluation sequence. */
+                                     * sediment stacks and prior draws of the reference's parametrisations come
+                                     * out bit-identical in both modes (1.3e10 phase velocities with the final
+                                     * rules, 2.9e10 with their predecessors); on unphysical stacks (layers of
+                                     * 0.1-0.3 km/s at periods of 20-300 s) the two modes differ at 3e-8 per
+                                     * value, where fp32 round-off decides the sign of the secular function just
+                                     * above the top layer's Vs and the exact scan of this library and the
+                                     * reference's already disagree.  The flag is there for callers who want the
+                                     * reference's evaluation sequence. */
 #define SURFDISP_PHASE_ONLY    0x10 /* OR into `kind` of the batched entries: phase velocities only
                                      * (what Point.misfit consumes, point.py:18); u is not written
                                      * and may be NULL */

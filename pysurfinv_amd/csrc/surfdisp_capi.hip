@@ -183,7 +183,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     float wtol = 1.2e-3f, atol = 1.0e-6f;
     if (const char *e = getenv("SURFDISP_WTOL")) wtol = (float)atof(e);
     if (const char *e = getenv("SURFDISP_ATOL")) atol = (float)atof(e);
-    float phimax = 1.5707963f;                             // developer knob, see DESIGN.md section 6 "The scan"
+    float phimax = 0.7853982f;                             // developer knob, see DESIGN.md section 6 "The scan"
     if (const char *e = getenv("SURFDISP_SCAN_PHASE")) phimax = (float)atof(e);
     sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, phase_only ? nullptr : w.ratio, w.nsolved, status, wtol, atol,
                      fastscan ? 1 : 0, w.fsafe, (!phase_only && use_overlap(Lmax, G)) ? 1 : 0, phimax};

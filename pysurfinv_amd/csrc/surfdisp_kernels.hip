@@ -459,6 +459,10 @@ __device__ __forceinline__ int drop_layers(const float *wq, const int Lcap, cons
 }
 
 // ================================================================================== K1: phase
+#ifdef SD_STATS
+// developer build (make stats): pass counters of the root search, read through surfdisp_stats() in this file
+__device__ unsigned long long g_stats[24];
+#endif
 enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3 };
 
 
@@ -646,10 +650,12 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
             guard = (cj < 0.8f * b1top) || !(cj < W_B(mmj - 1) + 0.3f);
         // coarse pass: the interval (previous coarse point, this one) may be skipped only if the
         // secular function has the same sign at both ends, was evaluated with the same effective
-        // half space at three consecutive coarse points around it, and bends so little over them
-        // (second difference < 2 x the smaller end value; a dip to zero inside would need ~8 x) that
-        // no pair of roots can hide in it.  Anything else is rescanned point by point.
+        // half space at the coarse points around it, and ln|Delta| bends so little at BOTH ends of the
+        // interval that no pair of roots can hide in it.  Anything else is rescanned point by point.
         bool uncert = false, back0 = false;
+#ifdef SD_STATS
+        int why = 0;
+#endif
         if (fastok) {
         const int ln1 = (lane + 1) & 63, lm2 = (lane + 62) & 63;
         const float nx_d = __shfl(val, ln1), sp_d = __shfl(val, lm2);
@@ -657,8 +663,9 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         const float sphi = __shfl(phj, lm1), nphi = __shfl(phj, ln1);
         // ln(p n / m^2) < 1 for three same-sign values: the second difference of ln|Delta| at the middle point.
         // A pair of roots between two coarse points lifts it to >= 2.2 at one of them whatever exponential
-        // envelope multiplies the function (soft layers: e^{k d} factors change Delta by orders of magnitude
-        // per coarse step and hide a sign-changing hump from the linear test below)
+        // envelope multiplies the function (soft layers: e^{k d} factors change Delta by orders of magnitude per
+        // coarse step; a test on the second difference of Delta itself, r01i-r01l, is blind there and fires
+        // before most simple roots instead)
         auto logsd_ok = [](float p, float m, float n) {
             const float rm = __builtin_amdgcn_rcpf(m);
             const float a = p * rm, b = n * rm;
@@ -669,18 +676,15 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
             const bool has_pp = (j >= 1) || q0ok;
             const float pp_d = (j >= 2) ? sp_d : ((j == 1) ? p0d : q0d);
             const int pp_mm = (j >= 2) ? sp_mm : ((j == 1) ? p0mm : q0mm);
-            const float lim = 2.0f * fminf(fabsf(pd), fabsf(val));
             // right end: with the next point (a last lane's right end is looked at by lane 0 of the next pass, back0
             // below).  A next point of the other sign means a root in the NEXT interval; two more in this one
             // would be three modes within two intervals, which the phase rule excludes.
             const bool nx_same = (negnan(nx_d) == negnan(val));
             const bool okf = !has_next || ((pmm == mmj) && (mmj == nx_mm) && fin(nx_d) &&
-                                           (fabsf(pd - 2.0f * val + nx_d) < lim) &&
                                            (nx_same ? logsd_ok(pd, val, nx_d) : (fabsf(nphi - phj) < A.phimax)));
             // left end: with the coarse point before ...
             const bool oklog_b = has_pp && logsd_ok(pp_d, pd, val);
-            const bool okb = !has_pp || ((pp_mm == pmm) && (pmm == mmj) && fin(pp_d) &&
-                                         (fabsf(pp_d - 2.0f * pd + val) < lim) && oklog_b);
+            const bool okb = !has_pp || ((pp_mm == pmm) && (pmm == mmj) && fin(pp_d) && oklog_b);
             // ... or, in the first coarse pass after fine ones, with the fine point before p0: the slope of
             // ln|Delta| over the last fine step against the slope over this interval (a pair close behind p0
             // bends it by 1.2-2.3 per fine step; 0.5 is allowed)
@@ -696,13 +700,20 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
             const bool near_hs = !(cj < W_B(mmj - 1) - 2.0f * (float)FSTRIDE * DC);
             // ... and the interval must be too short for two modes: consecutive modes are ~pi apart in the
             // vertical phase summed over the oscillatory layers, however the stack is built (thick or slow
-            // layers, short periods); the interval may add at most A.phimax (pi/2 by default) to it
+            // layers, short periods); the interval may add at most A.phimax (pi/4 by default) to it
             const float pphi = (j == 0) ? p0phi : sphi;
             const bool okphi = fabsf(phj - pphi) < A.phimax;
             uncert = near_hs || !(okf && okb && oke && okphi && fin(pd) && fin(val));
             // lane 0 also holds the right end of the previous pass's last interval (q0, p0): if that fails the
             // rescan starts at q0
             back0 = (j == 0) && q0ok && (cross ? !okphi : !oklog_b);
+#ifdef SD_STATS
+            {
+                const bool mmch = !((pmm == mmj) && (!has_next || mmj == nx_mm) && (!has_pp || pp_mm == pmm));
+                const bool lg = (has_next && nx_same && !logsd_ok(pd, val, nx_d)) || (has_pp && !oklog_b);
+                why = near_hs ? 3 : mmch ? 4 : lg ? 6 : !okphi ? 7 : !oke ? 8 : uncert ? 9 : 0;
+            }
+#endif
         }
         }
         const bool ev = searching && (cross || guard || uncert);
@@ -715,6 +726,19 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         const int e_pmm = __shfl(pmm, src);
         const int l_mm = __shfl(mmj, tbase + G - 1);
         const int e_cross = __shfl((int)cross, src);
+#ifdef SD_STATS
+        {
+            auto cnt = [&](int idx, bool pred) {
+                const unsigned long long m = __ballot(pred && j == 0);
+                if (lane == 0 && m) atomicAdd(&g_stats[idx], (unsigned long long)__popcll(m));
+            };
+            const int e_why = __shfl(cross ? 1 : (guard ? 2 : why), src);
+            const bool cs = fastok && coarse && st == ST_SCAN;
+            cnt(0, st == ST_SCAN); cnt(1, st == ST_REFINE); cnt(2, st == ST_ELLIP); cnt(5, cs); cnt(6, cs && fl >= 0 && !e_cross);
+            for (int r = 1; r <= 9; ++r) cnt(8 + r, cs && fl >= 0 && e_why == r);
+            cnt(18, cs && fl == tbase && __shfl((int)back0, tbase) != 0);
+        }
+#endif
         const int t_back0 = __shfl((int)back0, tbase);
         const int lastl = tbase + G - 1;
         const float l_c = __shfl(cj, lastl), l_d = __shfl(val, lastl);
@@ -751,9 +775,8 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
                 p0c = e_pc; p0d = e_pd; p0mm = e_pmm;
                 const bool e_back = (fl == tbase) && (t_back0 != 0);
                 if (e_back) { p0c = q0c; p0d = q0d; p0mm = q0mm; }
-                // an interval that merely failed the certificate usually sits just below the root (the
-                // smaller end value is what the curvature is compared with): stay on the fine grid for
-                // the next interval too instead of spending a coarse pass on finding the sign change there
+                // after a failed certificate stay on the fine grid for the next interval too (a restart at q0
+                // has two intervals to cover; a change of the layer dropping usually sits close to the root)
                 coarse = false; fine_left = (e_cross && !e_back) ? FSTRIDE : 2 * FSTRIDE; q0ok = false;
             } else {
                 q0c = pl_c; q0d = pl_d; q0mm = pl_mm; q0ok = true;
@@ -841,6 +864,9 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
                 solved = true;
             }
         }
+#ifdef SD_STATS
+        { const unsigned long long m = __ballot(solved && j == 0); if (lane == 0 && m) atomicAdd(&g_stats[4], (unsigned long long)__popcll(m)); }
+#endif
         if (solved) {
             if (j == 0) {
                 A.c[(size_t)k * B + b] = croot;                // period-major: coalesced across teams
@@ -1628,3 +1654,13 @@ hipError_t launch_group(hipStream_t s, int kind, const GroupArgs &a)
 }
 
 }  // namespace sd
+
+#ifdef SD_STATS
+extern "C" void surfdisp_stats(unsigned long long *out, int reset)
+{
+    unsigned long long z[24] = {0};
+    if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(sd::g_stats), z, sizeof(z)); return; }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(sd::g_stats), sizeof(z));
+}
+#endif

@@ -6,7 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsurfdisp_oracle.so"))
 fp = ctypes.POINTER(ctypes.c_float); ip = ctypes.POINTER(ctypes.c_int)
-S = np.load(os.path.join(ROOT, "gpurun_out", "scanfail.npy"), allow_pickle=True)
+S = np.load(os.path.join(ROOT, "gpurun_out", os.environ.get("SCANFAIL", "scanfail.npy")), allow_pickle=True)
 nshow = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 for idx, s in enumerate(S[:nshow]):
     m = np.ascontiguousarray(s["model"], np.float32); per = np.ascontiguousarray(s["per"], np.float32)

@@ -12,6 +12,8 @@ L = _lib.lib()
 rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "0")))
 T_END = time.time() + float(os.environ.get("SOAK_SECONDS", "120"))
 MONO = os.environ.get("SOAK_MONO", "1") == "1"
+ONLY = os.environ.get("SOAK_ONLY")                      # 'wild': that family only
+VSMIN = float(os.environ.get("SOAK_WILD_VSMIN", "0.1"))
 T_LAST = time.time()
 nst = nval = ndif = npat = ncase = 0
 byfam = {}
@@ -34,17 +36,17 @@ while time.time() < T_END:
     noise = float(rng.choice([0.02, 0.05, 0.1, 0.2])); tt = float(rng.choice([30., 60., 120., 200., 400.]))
     mono = True if MONO else bool(rng.random() < 0.5)
     m = synth.synth_models(B, Ln, seed=int(rng.integers(1 << 30)), noise=noise, monotone=mono, total_thickness=tt)
-    if rng.random() < 0.2 and Ln >= 4:
+    if ONLY is None and rng.random() < 0.2 and Ln >= 4:
         m[:, 1, 0] = 0.0; m[:, 0, 0] = 1.475; m[:, 2, 0] = 1.027; m[:, 4, 0] = 1e-4; m[:, 3, 0] = rng.uniform(0.3, 4.0, B); fam = 'water'
-    elif rng.random() < 0.3 and Ln >= 4:
+    elif ONLY is None and rng.random() < 0.3 and Ln >= 4:
         # soft sediments over rock: strong contrast, fundamental and first overtone nearly touch (osculation)
         m = synth.sediment_models(B, Ln, seed=int(rng.integers(1 << 30)), noise=noise, total_thickness=tt,
                                   max_layers=int(rng.choice([4, 4, 12])), water=bool(rng.random() < 0.3))
         plo, phi = 0.3, 30.0; fam = 'sediment'
-    elif rng.random() < 0.3:
+    elif ONLY == 'wild' or rng.random() < 0.3:
         # anything monotone: velocities 0.1-5 km/s, thicknesses 10 m - 50 km and periods 0.1-300 s log-uniform,
         # Vp/Vs 1.5-8, sometimes under water
-        vs = np.sort(np.exp(rng.uniform(np.log(0.1), np.log(5.0), (B, Ln))), axis=1)
+        vs = np.sort(np.exp(rng.uniform(np.log(VSMIN), np.log(5.0), (B, Ln))), axis=1)
         vp = np.sort(vs * np.exp(rng.uniform(np.log(1.5), np.log(8.0), (B, Ln))), axis=1)
         m[:, 1, :] = vs; m[:, 0, :] = vp; m[:, 2, :] = np.sort(rng.uniform(1.6, 3.4, (B, Ln)), axis=1)
         m[:, 3, :] = np.exp(rng.uniform(np.log(0.01), np.log(50.0), (B, Ln))); m[:, 3, -1] = 0.0
@@ -54,7 +56,7 @@ while time.time() < T_END:
             m[:, 0, 1:] = np.maximum(m[:, 0, 1:], 1.475); m[:, 2, 1:] = np.maximum(m[:, 2, 1:], 1.1)
         plo, phi = 0.1, 300.0; fam = 'wild'
     nl_t = None
-    if rng.random() < 0.15:
+    if ONLY is None and rng.random() < 0.15:
         fam = str(rng.choice(list(PRIOR))); mb, mc = PRIOR[fam]
         md_t, nl_t = mb.to_model(mc.reset(B)); md_t = md_t.contiguous()
         m = md_t.cpu().numpy(); Ln = m.shape[2]

@@ -438,8 +438,8 @@ def test_default_scan_random_stacks_and_independent_mode(hip):
 
 def test_default_scan_soft_sediments_over_rock(hip):
     """Soft sediments over rock at short periods: fundamental and first higher mode 0.02 km/s apart, e^{kd} factors
-    of many orders of magnitude in the secular function (the linear curvature test alone let 5e-5 of these values
-    slip; the vertical-phase rule and the log-domain test close it).  ~1.5 M phase velocities, bit-identical."""
+    of many orders of magnitude in the secular function (a curvature test on the function itself let 5e-5 of these
+    values slip; the vertical-phase rule and the test on ln|Delta| close it).  ~1.5 M phase velocities, bit-identical."""
     from pysurfinv_amd import synth, _lib
     rng = np.random.default_rng(78)
     try:
