@@ -66,7 +66,7 @@ extern "C" {
                                      * Teams of 16+ lanes always scan exactly.  Differential soaks
                                      * (scripts/soak_scan.py): random rough / water-covered / thick / soft-
                                      * sediment stacks and prior draws of the reference's parametrisations come
-                                     * out bit-identical in both modes (1.6e10 phase velocities with the final
+                                     * out bit-identical in both modes (1.8e10 phase velocities with the final
                                      * rules, 2.9e10 with their predecessors); on unphysical stacks (layers of
                                      * 0.1-0.3 km/s at periods of 20-300 s) the two modes differ at 3e-8 per
                                      * value, where fp32 round-off decides the sign of the secular function just

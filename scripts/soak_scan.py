@@ -12,7 +12,7 @@ L = _lib.lib()
 rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "0")))
 T_END = time.time() + float(os.environ.get("SOAK_SECONDS", "120"))
 MONO = os.environ.get("SOAK_MONO", "1") == "1"
-ONLY = os.environ.get("SOAK_ONLY")                      # 'wild': that family only
+ONLY = os.environ.get("SOAK_ONLY")                      # 'wild' / 'sediment': that family only (sediment: wider ranges)
 VSMIN = float(os.environ.get("SOAK_WILD_VSMIN", "0.1"))
 T_LAST = time.time()
 nst = nval = ndif = npat = ncase = 0
@@ -38,11 +38,18 @@ while time.time() < T_END:
     m = synth.synth_models(B, Ln, seed=int(rng.integers(1 << 30)), noise=noise, monotone=mono, total_thickness=tt)
     if ONLY is None and rng.random() < 0.2 and Ln >= 4:
         m[:, 1, 0] = 0.0; m[:, 0, 0] = 1.475; m[:, 2, 0] = 1.027; m[:, 4, 0] = 1e-4; m[:, 3, 0] = rng.uniform(0.3, 4.0, B); fam = 'water'
-    elif ONLY is None and rng.random() < 0.3 and Ln >= 4:
+    elif (ONLY is None and rng.random() < 0.3 and Ln >= 4) or (ONLY == 'sediment' and Ln >= 4):
         # soft sediments over rock: strong contrast, fundamental and first overtone nearly touch (osculation)
         m = synth.sediment_models(B, Ln, seed=int(rng.integers(1 << 30)), noise=noise, total_thickness=tt,
                                   max_layers=int(rng.choice([4, 4, 12])), water=bool(rng.random() < 0.3))
         plo, phi = 0.3, 30.0; fam = 'sediment'
+        if ONLY == 'sediment':                              # thicker and stiffer sediments, longer periods
+            f = rng.uniform(1.0, 3.0, (B, 1)); g = rng.uniform(1.0, 1.8, (B, 1))
+            rock = m[:, 1, :] > 2.9
+            m[:, 3, :] = np.where(rock, m[:, 3, :], m[:, 3, :] * f)
+            m[:, 1, :] = np.where(rock | (m[:, 1, :] == 0.0), m[:, 1, :], np.minimum(m[:, 1, :] * g, 2.85))
+            m[:, 1, :] = np.sort(m[:, 1, :], axis=1); m[:, 0, :] = np.sort(np.maximum(m[:, 0, :], 1.5 * m[:, 1, :]), axis=1)
+            plo, phi = 0.5, 60.0
     elif ONLY == 'wild' or rng.random() < 0.3:
         # anything monotone: velocities 0.1-5 km/s, thicknesses 10 m - 50 km and periods 0.1-300 s log-uniform,
         # Vp/Vs 1.5-8, sometimes under water
