@@ -79,3 +79,16 @@ def test_synth_generator_is_deterministic_and_shaped():
     assert (np.diff(a[:, 1], axis=1) >= 0).all()
     w = synth.water_models(3)
     assert (w[:, 1, 0] == 0).all()
+
+
+def test_sediment_family_is_monotone_and_deterministic():
+    """synth.sediment_models feeds the certified-scan GPU test and the scan soak: Vs and Vp never decrease with
+    depth (otherwise the root search scans exactly and the test proves nothing), same seed -> same stacks."""
+    from pysurfinv_amd import synth
+    for kw in ({}, dict(max_layers=12), dict(water=True), dict(max_layers=12, water=True)):
+        m = synth.sediment_models(256, 14, seed=7, **kw)
+        assert m.shape == (256, 5, 14) and m.dtype == np.float32
+        assert np.all(np.diff(m[:, 1, :], axis=1) >= 0) and np.all(np.diff(m[:, 0, :], axis=1) >= 0)
+        assert np.all(m[:, 0, :] > 0) and np.all(m[:, 2, :] > 0) and np.all(m[:, 3, :] >= 0)
+        assert np.all(m[:, 1, 1] < 3.0)                             # soft on top of the rock stack
+        assert np.array_equal(m, synth.sediment_models(256, 14, seed=7, **kw))

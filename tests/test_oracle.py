@@ -78,3 +78,31 @@ def test_work_model_delta_evaluations(ref_cases):
     m = d["model"][0]
     r = cport.forward(m[0], m[1], m[2], m[3], m[4], d["periods"], 2)
     assert 700 < r["n_delta"] < 1500
+
+
+def test_scan_trace_brackets_the_oracle_root(ref_cases):
+    """Developer aid ``surfdisp_oracle_scan_trace`` (scripts/dev_scanfail.py): the walk it records for period k
+    starts at 0.9 c(k-1), advances on the fp32 0.01 km/s grid and its first sign change brackets the oracle's c(k)."""
+    import ctypes
+    L = cport.lib()
+    fp = ctypes.POINTER(ctypes.c_float); ip = ctypes.POINTER(ctypes.c_int)
+    d = ref_cases["synth_L10_R"]
+    m = np.ascontiguousarray(d["model"][0], np.float32); per = np.ascontiguousarray(d["periods"], np.float32)
+    c_ref = d["c"][0]
+    rows = [np.ascontiguousarray(m[i]) for i in range(5)]
+    for k in (0, 3, len(per) - 1):
+        cap = 2000
+        ct = np.zeros(cap, np.float32); dt = np.zeros(cap, np.float32); mt = np.zeros(cap, np.int32)
+        n = L.surfdisp_oracle_scan_trace(m.shape[1], int(d["kind"]), *[r.ctypes.data_as(fp) for r in rows],
+                                         per.ctypes.data_as(fp), len(per), k, 8,
+                                         ct.ctypes.data_as(fp), dt.ctypes.data_as(fp), mt.ctypes.data_as(ip), cap)
+        assert 10 < n <= cap
+        if k:
+            assert ct[0] == np.float32(0.9) * c_ref[k - 1]
+        step = np.diff(ct[:n])
+        assert np.all(np.abs(step - 0.01) < 1e-5)
+        sg = np.signbit(dt[:n])
+        first = int(np.nonzero(sg[1:] != sg[:-1])[0][0])
+        assert n - (first + 2) == 8                                # eight points recorded past the bracket
+        assert ct[first] <= c_ref[k] <= ct[first + 1]
+        assert np.all((mt[:n] >= 2) & (mt[:n] <= m.shape[1]))
