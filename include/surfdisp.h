@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SURFDISP_ABI_VERSION 1
+#define SURFDISP_ABI_VERSION 2
 #define SURFDISP_NPER_MAX 200      /* fast_surf.pyf:14-19: cvper and outputs are real*4[200] */
 #define SURFDISP_NLAY_MAX 200      /* layers per stack accepted by this library */
 
@@ -48,31 +48,18 @@ extern "C" {
                                      * second batch of this size in flight on another stream, so the lanes per
                                      * stack are chosen for twice the stacks (fewer lanes per stack waste fewer
                                      * trial velocities; with one batch alone they would leave SIMDs idle) */
-#define SURFDISP_EXACTSCAN     0x80 /* OR into `kind`: evaluate the secular function at EVERY 0.01 km/s grid point
-                                     * from 0.9 c(k-1) up to the first sign change, as the reference does
-                                     * (calcul.f:143-166).  By default the search steps over four grid points at
-                                     * a time where that provably-in-practice cannot hide a pair of roots and
-                                     * rescans point by point everywhere else, so the bracket is found on the
-                                     * same fp32 grid with ~45 % fewer evaluations: an interval is skipped only
-                                     * (a) on stacks whose Vs and Vp never decrease with depth and whose layers
-                                     * are at most three wavelengths thick (no channel waves), (b) away from the
-                                     * half-space velocity (the one branch point of the secular function),
-                                     * (c) when the interval adds less than pi/4 to the vertical phase
-                                     * sum k d sqrt(c^2/v^2 - 1) over the oscillatory layers (consecutive overtones
-                                     * are ~pi apart in it), (d) when the coarse values around it have the same
-                                     * sign and layer dropping and the second difference of ln|Delta| is below 1
-                                     * at BOTH ends of the interval (a hidden pair of roots lifts it to >= 2.2 at
-                                     * one end whatever e^{kd} envelope multiplies the function).
-                                     * Teams of 16+ lanes always scan exactly.  Differential soaks
-                                     * (scripts/soak_scan.py): random rough / water-covered / thick / soft-
-                                     * sediment stacks and prior draws of the reference's parametrisations come
-                                     * out bit-identical in both modes (1.8e10 phase velocities with the final
-                                     * rules, 2.9e10 with their predecessors); on unphysical stacks (layers of
-                                     * 0.1-0.3 km/s at periods of 20-300 s) the two modes differ at 3e-8 per
-                                     * value, where fp32 round-off decides the sign of the secular function just
-                                     * above the top layer's Vs and the exact scan of this library and the
-                                     * reference's already disagree.  The flag is there for callers who want the
-                                     * reference's evaluation sequence. */
+#define SURFDISP_EXACTSCAN     0x80 /* accepted and ignored (ABI 1 spelling): the point-by-point scan is the default */
+#define SURFDISP_FASTSCAN      0x100 /* OR into `kind`: OPT-IN heuristic scan.  By default the secular function is
+                                     * evaluated at EVERY 0.01 km/s grid point from 0.9 c(k-1) up to the first sign
+                                     * change, as the reference does (calcul.f:143-166).  With this flag teams of
+                                     * 2..8 lanes step over four grid points at a time where a set of smoothness and
+                                     * mode-spacing tests (DESIGN.md "fast scan") finds no room for a pair of roots,
+                                     * and rescan point by point elsewhere: ~45 % fewer evaluations.  It is a measured
+                                     * argument, not a proof: differential soaks found 146 of 4.7e9 phase velocities
+                                     * (layers of 0.1-0.3 km/s at periods of 20-300 s) where the two scans return
+                                     * different roots or a different zero pattern.  Callers who need the reference's
+                                     * root selection on every input leave it off.  Also switched on for every call of
+                                     * the process by the environment variable SURFDISP_FASTSCAN=1 (read once). */
 #define SURFDISP_PHASE_ONLY    0x10 /* OR into `kind` of the batched entries: phase velocities only
                                      * (what Point.misfit consumes, point.py:18); u is not written
                                      * and may be NULL */

@@ -17,7 +17,8 @@ KIND_LOVE, KIND_RAYLEIGH = 1, 2
 PHASE_ONLY = 0x10
 INDEPENDENT = 0x20
 PIPELINED = 0x40
-EXACTSCAN = 0x80
+EXACTSCAN = 0x80        # ABI 1 spelling, accepted and ignored: the point-by-point scan is the default
+FASTSCAN = 0x100        # opt-in heuristic scan (include/surfdisp.h)
 NPER_MAX, NLAY_MAX = 200, 200
 
 # every symbol include/surfdisp.h declares

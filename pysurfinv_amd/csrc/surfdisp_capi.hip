@@ -5,13 +5,38 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include "surfdisp_internal.h"
 
 namespace {
 
 thread_local char g_err[512] = "";
-int g_team_override = 0;
-double *g_dbg = nullptr;    // developer hook, see surfdisp_debug_buffer
+// process-wide tuning state (surfdisp_set_team / surfdisp_debug_buffer): atomics, so concurrent callers race
+// benignly; a launch reads each value once
+std::atomic<int> g_team_override{0};
+std::atomic<double *> g_dbg{nullptr};    // developer hook, see surfdisp_debug_buffer
+
+// environment knobs, read ONCE per process (a getenv per launch is visible in launch-bound Metropolis loops)
+struct EnvKnobs {
+    int team = 0;                 // SURFDISP_TEAM
+    size_t overlap_max = 64u * 1024u;   // SURFDISP_OVERLAP_MAX
+    float refine_wtol = 1.2e-3f;  // SURFDISP_WTOL
+    float refine_atol = 1.0e-6f;  // SURFDISP_ATOL
+    float phimax = 0.7853982f;    // SURFDISP_SCAN_PHASE (fast scan only; developer knob)
+    bool fastscan = false;        // SURFDISP_FASTSCAN=1: opt every call of the process into the heuristic scan
+    int device = 0;               // SURFDISP_DEVICE (fast_surf_)
+    EnvKnobs()
+    {
+        if (const char *e = getenv("SURFDISP_TEAM")) team = atoi(e);
+        if (const char *e = getenv("SURFDISP_OVERLAP_MAX")) overlap_max = (size_t)atol(e);
+        if (const char *e = getenv("SURFDISP_WTOL")) refine_wtol = (float)atof(e);
+        if (const char *e = getenv("SURFDISP_ATOL")) refine_atol = (float)atof(e);
+        if (const char *e = getenv("SURFDISP_SCAN_PHASE")) phimax = (float)atof(e);
+        if (const char *e = getenv("SURFDISP_FASTSCAN")) fastscan = atoi(e) != 0;
+        if (const char *e = getenv("SURFDISP_DEVICE")) device = atoi(e);
+    }
+};
+const EnvKnobs &knobs() { static const EnvKnobs k; return k; }
 
 void set_err(const char *fmt, const char *a = "", const char *b = "")
 {
@@ -26,6 +51,9 @@ void set_err(const char *fmt, const char *a = "", const char *b = "")
             return SURFDISP_ERR_HIP;                                         \
         }                                                                    \
     } while (0)
+
+constexpr int SD_KIND_FLAGS = SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED | SURFDISP_EXACTSCAN |
+                             SURFDISP_FASTSCAN;
 
 size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -54,11 +82,8 @@ Carve carve(void *base, int B, int Lmax, int P)
 
 int pick_team(int B, int Lmax, bool need_ratio = true)
 {
-    int G = g_team_override;
-    if (G == 0) {
-        const char *e = getenv("SURFDISP_TEAM");
-        if (e) G = atoi(e);
-    }
+    int G = g_team_override.load(std::memory_order_relaxed);
+    if (G == 0) G = knobs().team;
     if (G == 0) {
         // measured on MI355X (scripts/dev_overlap.py): batches of 16 384 stacks and
         // more want ~4 wavefronts per SIMD (262 144 lanes on 256 CUs x 4 SIMDs), smaller ones ~2, tiny
@@ -86,15 +111,14 @@ int pick_team(int B, int Lmax, bool need_ratio = true)
 // (measured: on at 49 KB is 7-19 % faster than off, on at 74 KB / 147 KB is 9 % / 38 % slower).
 static bool use_overlap(int Lmax, int G)
 {
-    size_t cap = 64u * 1024u;
-    if (const char *e = getenv("SURFDISP_OVERLAP_MAX")) cap = (size_t)atol(e);
+    const size_t cap = knobs().overlap_max;
     return G >= 4 && sd::phase_lds_bytes(Lmax, G, true) * (256 / SD_PHASE_BLOCK) <= cap;
 }
 
 int check_args(int B, int Lmax, int P, int kind, const void *model, const void *per,
                const void *c, const void *u)
 {
-    const int wave = kind & ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED | SURFDISP_EXACTSCAN);
+    const int wave = kind & ~SD_KIND_FLAGS;
     if (B < 1 || Lmax < 2 || Lmax > SURFDISP_NLAY_MAX || P < 1 || P > SURFDISP_NPER_MAX ||
         (wave != SURFDISP_KIND_LOVE && wave != SURFDISP_KIND_RAYLEIGH) || !model || !per || !c ||
         (!u && !(kind & SURFDISP_PHASE_ONLY))) {
@@ -136,7 +160,7 @@ int surfdisp_set_team(int lanes)
         set_err("team must be 0 or a power of two <= 64");
         return SURFDISP_ERR_INVALID;
     }
-    g_team_override = lanes;
+    g_team_override.store(lanes, std::memory_order_relaxed);
     return SURFDISP_SUCCESS;
 }
 
@@ -144,7 +168,7 @@ int surfdisp_get_team(int B, int Lmax) { return pick_team(B, Lmax); }
 
 // developer hook (not in include/surfdisp.h): device buffer of B*P*16 doubles receiving
 // group-velocity intermediates of the next launches; nullptr switches it off.
-void surfdisp_debug_buffer(double *dev) { g_dbg = dev; }
+void surfdisp_debug_buffer(double *dev) { g_dbg.store(dev, std::memory_order_relaxed); }
 
 size_t surfdisp_workspace_bytes(int B, int Lmax, int P)
 {
@@ -168,8 +192,11 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     const bool phase_only = (kind & SURFDISP_PHASE_ONLY) != 0;
     const bool indep = (kind & SURFDISP_INDEPENDENT) != 0;
     const bool pipelined = (kind & SURFDISP_PIPELINED) != 0;
-    const bool fastscan = (kind & SURFDISP_EXACTSCAN) == 0;     // certified coarse-to-fine scan unless opted out
-    kind &= ~(SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED | SURFDISP_EXACTSCAN);
+    // the reference's point-by-point scan unless the caller (flag) or the process (environment) opted into the
+    // heuristic one; SURFDISP_EXACTSCAN (ABI 1) is accepted and wins over both
+    const EnvKnobs &kn = knobs();
+    const bool fastscan = ((kind & SURFDISP_FASTSCAN) != 0 || kn.fastscan) && (kind & SURFDISP_EXACTSCAN) == 0;
+    kind &= ~SD_KIND_FLAGS;
     const Carve w = carve(workspace, B, Lmax, P);
     // independent mode has B*P root searches in flight: size the teams for that many; a caller that
     // keeps a second batch in flight (SURFDISP_PIPELINED) has twice the stacks on the chip
@@ -180,16 +207,12 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     if (ev) SD_HIP(hipEventRecord(ev[0], s));
     SD_HIP(sd::launch_prep(s, kind, pa));
     if (ev) SD_HIP(hipEventRecord(ev[1], s));
-    float wtol = 1.2e-3f, atol = 1.0e-6f;
-    if (const char *e = getenv("SURFDISP_WTOL")) wtol = (float)atof(e);
-    if (const char *e = getenv("SURFDISP_ATOL")) atol = (float)atof(e);
-    float phimax = 0.7853982f;                             // developer knob, see DESIGN.md section 6 "The scan"
-    if (const char *e = getenv("SURFDISP_SCAN_PHASE")) phimax = (float)atof(e);
+    const float wtol = kn.refine_wtol, atol = kn.refine_atol, phimax = kn.phimax;
     sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, phase_only ? nullptr : w.ratio, w.nsolved, status, wtol, atol,
                      fastscan ? 1 : 0, w.fsafe, (!phase_only && use_overlap(Lmax, G)) ? 1 : 0, phimax};
     SD_HIP(sd::launch_phase(s, kind, G, indep, ph));
     if (ev) SD_HIP(hipEventRecord(ev[2], s));
-    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, g_dbg, kb, ka, kr};
+    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, g_dbg.load(std::memory_order_relaxed), kb, ka, kr};
     if (!phase_only) SD_HIP(sd::launch_group(s, kind, ga));
     sd::FinishArgs fa{B, P, w.ct, phase_only ? nullptr : w.ut, c, phase_only ? nullptr : u,
                       indep ? w.nsolved : nullptr, w.nl, status};
@@ -380,7 +403,14 @@ int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const f
         return SURFDISP_ERR_NO_DEVICE;
     }
     if (device < 0 || device >= ndev) { set_err("bad device ordinal"); return SURFDISP_ERR_INVALID; }
-    SD_HIP(hipSetDevice(device));
+    // run on `device`, then hand the calling thread back the device it had selected
+    struct DeviceScope {
+        int prev = -1;
+        ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } scope;
+    if (hipGetDevice(&scope.prev) != hipSuccess) scope.prev = -1;
+    if (scope.prev == device) scope.prev = -1;                 // nothing to restore
+    else SD_HIP(hipSetDevice(device));
     const size_t nm = (size_t)B * 5 * Lmax * sizeof(float);
     const size_t np = (size_t)P * sizeof(float);
     const size_t ni = (size_t)B * sizeof(int);
@@ -462,8 +492,7 @@ void fast_surf_(const int *n_layer, const int *kind,
     memcpy(model + 2 * n, rho, n * sizeof(float));
     memcpy(model + 3 * n, h, n * sizeof(float));
     memcpy(model + 4 * n, qsinv, n * sizeof(float));
-    int dev = 0;
-    if (const char *e = getenv("SURFDISP_DEVICE")) dev = atoi(e);
+    const int dev = knobs().device;
     const int rc = surfdisp_forward_batch(dev, 1, n, nullptr, model, P, per, *kind, c, u, nullptr);
     free(model);
     if (rc != SURFDISP_SUCCESS) {

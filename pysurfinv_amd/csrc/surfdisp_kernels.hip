@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <atomic>
 #include "surfdisp_internal.h"
 
 #define SD_HD __host__ __device__
@@ -895,7 +896,9 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         // period index is reduced over the stack's teams; the finish kernel applies it
         if (team_valid && j == 0 && n >= 2 && status != SURFDISP_OK) {
             A.c[(size_t)k_own * B + b] = 0.0f;
-            atomicMin(&A.nsolved[b], status == SURFDISP_NUMERIC ? 0 : k_own);
+            // -1: the secular function left the fp32 range somewhere in this stack (the finish kernel then
+            // reports SURFDISP_NUMERIC, as the faithful mode does)
+            atomicMin(&A.nsolved[b], status == SURFDISP_NUMERIC ? -1 : k_own);
         }
         return;
     }
@@ -1545,7 +1548,9 @@ __global__ __launch_bounds__(256) void surfdisp_finish_kernel(FinishArgs A)
         // independent mode: status word from the reduced first-failing period
         const int bb = b0 + threadIdx.x;
         const int ns = A.nsolved[bb];
-        if (A.status) A.status[bb] = (A.nl[bb] < 2) ? SURFDISP_BADMODEL : (ns >= P ? SURFDISP_OK : (ns == 0 ? SURFDISP_NOROOT : SURFDISP_PARTIAL));
+        if (A.status) A.status[bb] = (A.nl[bb] < 2) ? SURFDISP_BADMODEL
+                                     : (ns >= P ? SURFDISP_OK
+                                     : (ns < 0 ? SURFDISP_NUMERIC : (ns == 0 ? SURFDISP_NOROOT : SURFDISP_PARTIAL)));
     }
     for (int pass = 0; pass < 2; ++pass) {
         const float *src = pass ? A.ut : A.ct;
@@ -1573,15 +1578,27 @@ __global__ __launch_bounds__(256) void surfdisp_finish_kernel(FinishArgs A)
 // ======================================================================================= launch
 namespace {
 
+constexpr int SD_MAX_DEVICES = 64;
+
 template <int KIND, int G, bool INDEP, bool FAST = false>
 hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 {
     constexpr int S = SD_PHASE_BLOCK / G;
     const size_t lds = sd::phase_lds_bytes(a.Lmax, G, a.overlap != 0);
     auto kern = sd::surfdisp_phase_kernel<KIND, G, INDEP, FAST>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    // raise the dynamic-LDS limit of this instantiation only when a launch needs more than any before it (per
+    // device): the attribute call costs ~10 us, visible in launch-bound Metropolis loops
+    static std::atomic<size_t> lds_set[SD_MAX_DEVICES];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int di = (dev >= 0 && dev < SD_MAX_DEVICES) ? dev : 0;
+    if (lds > lds_set[di].load(std::memory_order_acquire) || dev != di) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        size_t cur = lds_set[di].load(std::memory_order_relaxed);
+        while (lds > cur && !lds_set[di].compare_exchange_weak(cur, lds, std::memory_order_release)) {}
+    }
     const long teams = INDEP ? (long)a.B * a.P : (long)a.B;
     const int grid = (int)((teams + S - 1) / S);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SD_PHASE_BLOCK), lds, s, a);

@@ -44,7 +44,7 @@ class MetropolisBatch:
     """
 
     def __init__(self, spec: ParamSpec, to_model, periods, c_obs, uncer, device="cuda:0",
-                 isgood=None, proposer=None, seed=None, forward=None, independent=False, exact_scan=False):
+                 isgood=None, proposer=None, seed=None, forward=None, independent=False, fast_scan=False):
         import torch
         self.torch = torch
         self.device = torch.device(device)
@@ -63,8 +63,9 @@ class MetropolisBatch:
         # independent=True: period-parallel root search (SURFDISP_INDEPENDENT) - lower latency for few
         # chains; only for smooth parameterisations (no low-velocity roughness), see include/surfdisp.h
         self.independent = bool(independent)
-        # exact_scan=True: the reference's point-by-point scan (SURFDISP_EXACTSCAN)
-        self.exact_scan = bool(exact_scan)
+        # fast_scan=True: opt into the heuristic coarse-to-fine scan (SURFDISP_FASTSCAN); the default walks every
+        # grid point of the reference's scan, so root selection and failures are the reference's on every input
+        self.fast_scan = bool(fast_scan)
         self.n_forward = 0
 
     # ------------------------------------------------------------------ forward + misfit
@@ -80,7 +81,7 @@ class MetropolisBatch:
         if self._plan is None or (self._plan.B, self._plan.L) != (C, L):
             self._plan = BatchPlan(C, L, self.periods.numel(), device=self.device)
         c, _, st = self._plan.run(model.contiguous(), self.periods, kind=_lib.KIND_RAYLEIGH | _lib.PHASE_ONLY,
-                                  nlay=nlay, independent=self.independent, exact_scan=self.exact_scan)
+                                  nlay=nlay, independent=self.independent, fast_scan=self.fast_scan)
         return c.to(torch.float64), st
 
     def misfit(self, params):

@@ -54,13 +54,13 @@ class Point:
         return float(mis[0]), float(chi[0]), float(L[0])
 
     def MCinvMP(self, outdir="MCtest", pid=None, runN=50000, chainL=1000, nprocess=None, seed=42,
-                priori=False, isgood=None, verbose=True, spec_depth=1, independent=False, exact_scan=False):
+                priori=False, isgood=None, verbose=True, spec_depth=1, independent=False, fast_scan=False):
         """``runN // chainL`` chains of ``chainL`` steps each, the first one started at the initial model
         (point.py:91-125); writes ``{outdir}/{pid}.npz`` and returns the mcTrack array [runN, 3 + N]."""
         if priori and outdir.split("_")[-1] != "priori":
             outdir = "_".join((outdir, "priori"))
         pid = self.pid if pid is None else pid
-        mc = self._sampler(seed=seed, isgood=isgood, independent=independent, exact_scan=exact_scan)
+        mc = self._sampler(seed=seed, isgood=isgood, independent=independent, fast_scan=fast_scan)
         track = mc.run(max(int(runN) // int(chainL), 1), int(chainL), init_first=True, priori=priori,
                        spec_depth=spec_depth)
         arr = track.cpu().numpy().reshape(-1, track.shape[-1])

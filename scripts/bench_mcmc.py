@@ -23,7 +23,7 @@ if os.environ.get("MCMC_MODEL", "cont") == "hybrid":
 else:
     mb = Model1DBatch(CONT, device=dev)
 IND = os.environ.get("MCMC_INDEPENDENT", "0") == "1"
-XS = os.environ.get("MCMC_EXACTSCAN", "0") == "1"
+XS = os.environ.get("MCMC_FASTSCAN", "0") == "1"
 for name, chains, steps, depth in (("configs[2] single point: 100 chains (100 000 steps = 100 x 1000)", 100, 61, 1),
                                    ("configs[2], speculative depth 3", 100, 61, 3),
                                    ("configs[2], speculative depth 4", 100, 61, 4),
@@ -31,13 +31,13 @@ for name, chains, steps, depth in (("configs[2] single point: 100 chains (100 00
                                    ("1 024 chains", 1024, 41, 1),
                                    ("1 024 chains, speculative depth 2", 1024, 41, 2),
                                    ("configs[3] per-GPU share: 512 points x 50 chains = 25 600 chains", 25600, 12, 1)):
-    mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], G["trace/c_obs"], G["trace/uncer"], device=dev, seed=0, independent=IND, exact_scan=XS)
+    mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], G["trace/c_obs"], G["trace/uncer"], device=dev, seed=0, independent=IND, fast_scan=XS)
     mc.run(chains, 1 + 2 * depth, spec_depth=depth); torch.cuda.synchronize()
     t0 = time.perf_counter(); tr = mc.run(chains, steps, spec_depth=depth); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     if depth == 1 and os.environ.get("MCMC_GRAPH", "1") == "1":
         mc.run_graphed(chains, 8); torch.cuda.synchronize()
         t0 = time.perf_counter(); trg = mc.run_graphed(chains, 203); torch.cuda.synchronize(); dtg = time.perf_counter() - t0
-        print(json.dumps({"independent": IND, "exact_scan": XS, "config": name + " [HIP graph]", "chains": chains,
+        print(json.dumps({"independent": IND, "fast_scan": XS, "config": name + " [HIP graph]", "chains": chains,
                           "metropolis_steps_per_s": chains * 203 / dtg, "ms_per_lockstep": dtg / 203 * 1e3,
                           "ms_params_to_stack": 0, "ms_forward_phase_only": 0, "accept_rate": float(trg[:, 1:, 2].mean())}), flush=True)
     # split: parameters -> stacks, forward, rest
@@ -48,7 +48,7 @@ for name, chains, steps, depth in (("configs[2] single point: 100 chains (100 00
     t1 = time.perf_counter()
     for _ in range(5): mc.forward_c(p)
     torch.cuda.synchronize(); t_fwd = (time.perf_counter() - t1) / 5 - t_model
-    print(json.dumps({"independent": IND, "exact_scan": XS, "config": name, "chains": chains, "steps_timed": steps, "spec_depth": depth, "layers": int(m.shape[2]),
+    print(json.dumps({"independent": IND, "fast_scan": XS, "config": name, "chains": chains, "steps_timed": steps, "spec_depth": depth, "layers": int(m.shape[2]),
                       "metropolis_steps_per_s": chains * steps / dt, "ms_per_lockstep": dt / steps * 1e3,
                       "ms_params_to_stack": t_model * 1e3, "ms_forward_phase_only": t_fwd * 1e3,
                       "accept_rate": float(tr[:, 1:, 2].mean())}), flush=True)

@@ -399,25 +399,25 @@ def test_fp32_overflow_fails_the_stack_like_the_reference(hip):
 
 
 @pytest.mark.parametrize("team", [2, 4, 8, 64])
-def test_default_scan_same_brackets_as_exact_scan_on_golden_cases(hip, ref_cases, team):
-    """Default scan (coarse steps over certified intervals, point-by-point rescans elsewhere) against
-    SURFDISP_EXACTSCAN (every grid point, as the reference): bit-identical outputs on every golden case,
-    the rough ones included (teams above 8 lanes always scan exactly)."""
+def test_fast_scan_same_brackets_as_default_scan_on_golden_cases(hip, ref_cases, team):
+    """Opt-in SURFDISP_FASTSCAN (coarse steps over intervals its tests find free of roots, point-by-point rescans
+    elsewhere) against the default scan (every grid point, as the reference): bit-identical outputs on every
+    golden case, the rough ones included (teams above 8 lanes always scan point by point)."""
     from pysurfinv_amd import _lib
     assert _lib.lib().surfdisp_set_team(team) == 0
     try:
         for name, d in ref_cases.items():
-            c0, u0, s0 = hip.forward_batch(d["model"], d["periods"], d["kind"], exact_scan=True)
-            c1, u1, s1 = hip.forward_batch(d["model"], d["periods"], d["kind"])
+            c0, u0, s0 = hip.forward_batch(d["model"], d["periods"], d["kind"])
+            c1, u1, s1 = hip.forward_batch(d["model"], d["periods"], d["kind"], fast_scan=True)
             assert np.array_equal(c0, c1) and np.array_equal(s0, s1), name
             assert np.array_equal(u0, u1, equal_nan=True), name
     finally:
         _lib.lib().surfdisp_set_team(0)
 
 
-def test_default_scan_random_stacks_and_independent_mode(hip):
-    """Random stacks (smooth and rough, with and without low-velocity layers, thin and thick): the
-    default scan is bit-identical to SURFDISP_EXACTSCAN; also under SURFDISP_INDEPENDENT."""
+def test_fast_scan_random_stacks_and_independent_mode(hip):
+    """Random stacks (smooth and rough, with and without low-velocity layers, thin and thick): the opt-in
+    fast scan is bit-identical to the default point-by-point scan; also under SURFDISP_INDEPENDENT."""
     from pysurfinv_amd import synth, _lib
     rng = np.random.default_rng(8)
     for it in range(12):
@@ -426,17 +426,17 @@ def test_default_scan_random_stacks_and_independent_mode(hip):
                                monotone=bool(it % 2), total_thickness=float(rng.choice([30., 60., 120., 200., 400.])))
         per = np.sort(rng.uniform(4.0, 120.0, int(rng.integers(5, 30)))).astype(np.float32)
         kind = 1 + it % 2
-        c0, u0, s0 = hip.forward_batch(m, per, kind, exact_scan=True)
-        c1, u1, s1 = hip.forward_batch(m, per, kind)
+        c0, u0, s0 = hip.forward_batch(m, per, kind)
+        c1, u1, s1 = hip.forward_batch(m, per, kind, fast_scan=True)
         assert np.array_equal(c0, c1) and np.array_equal(s0, s1) and np.array_equal(u0, u1, equal_nan=True)
     m = synth.synth_models(512, 10, seed=1)
     per = synth.default_periods(20)
-    c0, u0, s0 = hip.forward_batch(m, per, 2, independent=True, exact_scan=True)
-    c1, u1, s1 = hip.forward_batch(m, per, 2, independent=True)
+    c0, u0, s0 = hip.forward_batch(m, per, 2, independent=True)
+    c1, u1, s1 = hip.forward_batch(m, per, 2, independent=True, fast_scan=True)
     assert np.array_equal(c0, c1) and np.array_equal(s0, s1)
 
 
-def test_default_scan_soft_sediments_over_rock(hip):
+def test_fast_scan_soft_sediments_over_rock(hip):
     """Soft sediments over rock at short periods: fundamental and first higher mode 0.02 km/s apart, e^{kd} factors
     of many orders of magnitude in the secular function (a curvature test on the function itself let 5e-5 of these
     values slip; the vertical-phase rule and the test on ln|Delta| close it).  ~1.5 M phase velocities, bit-identical."""
@@ -450,8 +450,8 @@ def test_default_scan_soft_sediments_over_rock(hip):
                                       total_thickness=float(rng.choice([30., 120., 400.])))
             per = np.sort(rng.uniform(0.3, 30.0, 32)).astype(np.float32)
             for kind in (1, 2):
-                c0, u0, s0 = hip.forward_batch(m, per, kind | 0x10, exact_scan=True)
-                c1, u1, s1 = hip.forward_batch(m, per, kind | 0x10)
+                c0, u0, s0 = hip.forward_batch(m, per, kind | 0x10)
+                c1, u1, s1 = hip.forward_batch(m, per, kind | 0x10, fast_scan=True)
                 assert np.array_equal(c0, c1) and np.array_equal(s0, s1), (it, kind, int((c0 != c1).sum()))
     finally:
         _lib.lib().surfdisp_set_team(0)

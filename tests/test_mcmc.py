@@ -209,6 +209,6 @@ def test_point_dropin_on_gpu(tmp_path):
     assert arr.shape == (64 * 12, 16) and np.isfinite(arr).all()
     spec = p.initMod.spec
     assert (arr[:, 3:] > spec.vmin).all() and (arr[:, 3:] < spec.vmax).all()
-    arr2 = p.MCinvMP(outdir=str(tmp_path / "mc"), pid="1_3", runN=64 * 12, chainL=12, seed=3, spec_depth=3, exact_scan=True)
+    arr2 = p.MCinvMP(outdir=str(tmp_path / "mc"), pid="1_3", runN=64 * 12, chainL=12, seed=3, spec_depth=3, fast_scan=True)
     assert arr2.shape == arr.shape and np.isfinite(arr2).all()
     assert os.path.exists(tmp_path / "mc" / "1_3.npz")
