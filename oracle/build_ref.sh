@@ -19,6 +19,13 @@ mkdir -p "$OUT"
   -o "$OUT/libfast_surf_ref.so" \
   "$REF/fast_surf.f" "$REF/flat1.f" "$REF/init.f" "$REF/calcul.f" \
   "$REF/surfa.f" "$REF/mchdepsun.f"
+# second build of the same unmodified sources with FMA contraction: only used by
+# tests/golden/make_golden_spread.py to record how far the reference moves from ITSELF under another
+# legal compilation (defect 10) - the yardstick for ill-conditioned entries
+"$FLANG" -O2 -ffp-contract=fast -march=native -fPIC -shared -ffixed-line-length-none \
+  -o "$OUT/libfast_surf_ref_fma.so" \
+  "$REF/fast_surf.f" "$REF/flat1.f" "$REF/init.f" "$REF/calcul.f" \
+  "$REF/surfa.f" "$REF/mchdepsun.f"
 "$FLANG" --version | head -1 > "$OUT/BUILD_INFO.txt"
 echo "flags: -O2 -ffp-contract=off -fPIC -shared -ffixed-line-length-none" >> "$OUT/BUILD_INFO.txt"
 echo "built $OUT/libfast_surf_ref.so"

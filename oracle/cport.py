@@ -39,6 +39,9 @@ def lib():
         L.surfdisp_oracle_forward_batch.restype = ctypes.c_int
         L.surfdisp_oracle_forward_batch.argtypes = [ctypes.c_int, ctypes.c_int, ip, fp, ctypes.c_int,
                                                     fp, ctypes.c_int, fp, fp, ip, ctypes.c_int]
+        L.surfdisp_oracle_forward_at.restype = ctypes.c_int
+        L.surfdisp_oracle_forward_at.argtypes = [ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, fp,
+                                                 ctypes.c_int, fp, fp, fp]
         _lib = L
     return _lib
 
@@ -93,3 +96,20 @@ def forward_batch(model, periods, kind, nlay=None, nthreads=1):
                                         status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
                                         int(nthreads))
     return c, u, status
+
+
+def group_at(model, periods, kind, c_at, nlay=None):
+    """U[B,P] of the oracle's group-velocity computation (REIGEN / LEIGEN, with the ellipticity of calcul.f:195)
+    evaluated at the GIVEN phase velocities c_at[B,P] (entries <= 0: at the oracle's own root); also returns the
+    oracle's own c[B,P].  Test hook, see surfdisp_oracle_forward_at."""
+    model = np.ascontiguousarray(model, dtype=np.float32)
+    B, _, Lmax = model.shape
+    per = _f32(periods); P = per.size
+    c_at = np.ascontiguousarray(c_at, dtype=np.float32)
+    c = np.zeros((B, P), np.float32); u = np.zeros((B, P), np.float32)
+    for i in range(B):
+        n = int(nlay[i]) if nlay is not None else Lmax
+        m = np.ascontiguousarray(model[i, :, :n])
+        lib().surfdisp_oracle_forward_at(n, int(kind), _fp(m[0]), _fp(m[1]), _fp(m[2]), _fp(m[3]), _fp(m[4]),
+                                         _fp(per), P, _fp(c_at[i]), _fp(c[i]), _fp(u[i]))
+    return c, u

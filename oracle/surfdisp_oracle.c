@@ -50,6 +50,9 @@ typedef struct {
     /* developer trace of the scan of one period (surfdisp_oracle_scan_trace; not in the reference) */
     int tr_k, tr_cap, tr_n, tr_extra;
     float *tr_c, *tr_d; int *tr_mm;
+    /* test hook (surfdisp_oracle_forward_at; not in the reference): phase velocities at which the ellipticity
+     * and the group velocity of each period are evaluated instead of the oracle's own roots */
+    const float *c_at;
 } ctx_t;
 
 static inline float sgn1(float x) { return copysignf(1.0f, x); } /* SIGN(1.,x) */
@@ -320,9 +323,14 @@ static int nevill(ctx_t *s, float t, float c1, float c2, float del1, float del2,
         ic = ic + 1;
         if (!(ic < 50)) return 1;
         int bisect = 0;
-        /* surfa.f:32-34 : c3 must lie strictly inside (c1,c2) */
-        if (c1 <= c3) { if (c2 <= c3) bisect = 1; }
-        else          { if (c2 >= c3) bisect = 1; }
+        /* surfa.f:32-34 : c3 must lie strictly inside (c1,c2).  These are arithmetic IFs: a NaN expression is
+         * neither negative nor zero and takes the THIRD label (flang, like gfortran, lowers `if (x) l1,l2,l3` to
+         * x<0 -> l1, x==0 -> l2, else l3).  A NaN c3 (Neville step through a NaN end value) therefore goes
+         * 777 -> 1330 -> 1344: the reference falls back to BISECTION and keeps going - pinned bit for bit by
+         * tests/golden/ref_families.npz (overflow_R, wild_*), where the reference returns roots next to the
+         * edge of the overflowed region instead of exhausting its 50 cycles. */
+        if (c1 - c3 <= 0.0f) { if (c2 - c3 <= 0.0f) bisect = 1; }        /* 1320: if(c2-c3) 1344,1344,1000 */
+        else                 { if (!(c2 - c3 < 0.0f)) bisect = 1; }      /* 1330: if(c2-c3) 1000,1344,1344 */
         if (!bisect) {
             float s13 = del1 - del3;
             float s32 = del3 - del2;
@@ -782,7 +790,7 @@ static int forward_ctx(ctx_t *s, int nlay, int kind,
         (kind != 1 && kind != 2))
         return SURFDISP_ORACLE_EINVAL;
     const float pi = 3.1415927f, t_base = 1.0f, dc = 0.01f;
-    float c[SURFDISP_NPER_MAX], ratio[SURFDISP_NPER_MAX];
+    float c[SURFDISP_NPER_MAX], ratio[SURFDISP_NPER_MAX], cgrp[SURFDISP_NPER_MAX];
     int status = SURFDISP_ORACLE_OK;
     /* a new process sees zeroed COMMON blocks */
     memset(s->a, 0, 5 * NSZ * sizeof(float));
@@ -846,7 +854,8 @@ static int forward_ctx(ctx_t *s, int nlay, int kind,
             c1 = cn;
             if (c1 - s->b[s->mmax - 1] <= 0.0f) {
                 c[k] = c1;
-                if (ifunc == 2) ratio[k] = dltar(s, c1, t1, 3);
+                cgrp[k] = (s->c_at && s->c_at[k] > 0.0f) ? s->c_at[k] : c1;     /* test hook, see ctx_t */
+                if (ifunc == 2) ratio[k] = dltar(s, cgrp[k], t1, 3);
                 imax = k + 1;
                 continue;
             }
@@ -866,7 +875,7 @@ static int forward_ctx(ctx_t *s, int nlay, int kind,
             build_model(s, t, nlay);
             for (int i = 0; i < nlay; ++i) s->qs[i] = s->qs_ref[i];
             flat1(s->d, s->rho, s->a, s->b, nlay, kind);
-            float ugr = (kind == 2) ? reigen(s, t, c[lip], ratio[lip]) : leigen(s, t, c[lip]);
+            float ugr = (kind == 2) ? reigen(s, t, cgrp[lip], ratio[lip]) : leigen(s, t, cgrp[lip]);
             u_out[lip] = ugr;
             c_out[lip] = c[lip];
             if (ratio_out) ratio_out[lip] = ratio[lip];
@@ -885,7 +894,7 @@ int surfdisp_oracle_forward(int nlay, int kind,
 {
     ctx_t *s = (ctx_t *)malloc(sizeof(ctx_t));
     if (!s) return SURFDISP_ORACLE_EINVAL;
-    s->tr_c = NULL;
+    s->tr_c = NULL; s->c_at = NULL;
     int st = forward_ctx(s, nlay, kind, vp, vs, rho, h, qsinv, per, nper, c_out, u_out,
                          nsolved, n_delta_out, NULL);
     free(s);
@@ -919,9 +928,28 @@ int surfdisp_oracle_forward_dbg(int nlay, int kind,
 {
     ctx_t *s = (ctx_t *)malloc(sizeof(ctx_t));
     if (!s) return SURFDISP_ORACLE_EINVAL;
-    s->tr_c = NULL;
+    s->tr_c = NULL; s->c_at = NULL;
     int st = forward_ctx(s, nlay, kind, vp, vs, rho, h, qsinv, per, nper, c_out, u_out,
                          NULL, NULL, ratio_out);
+    free(s);
+    return st;
+}
+
+/* Test hook: the oracle's own root search, but ellipticity (calcul.f:195) and group velocity (REIGEN / LEIGEN) of
+ * period k evaluated at the GIVEN phase velocity c_at[k] (> 0; else at the oracle's root).  Answers "what does the
+ * reference's group-velocity computation return at the phase velocity another implementation found" - near osculating
+ * modes U changes by >1000x the relative change of c, so comparing U at slightly different c says nothing about the
+ * group-velocity arithmetic.  c_out = the oracle's own roots. */
+int surfdisp_oracle_forward_at(int nlay, int kind,
+                               const float *vp, const float *vs, const float *rho,
+                               const float *h, const float *qsinv,
+                               const float *per, int nper, const float *c_at,
+                               float *c_out, float *u_out)
+{
+    ctx_t *s = (ctx_t *)malloc(sizeof(ctx_t));
+    if (!s) return SURFDISP_ORACLE_EINVAL;
+    s->tr_c = NULL; s->c_at = c_at;
+    int st = forward_ctx(s, nlay, kind, vp, vs, rho, h, qsinv, per, nper, c_out, u_out, NULL, NULL, NULL);
     free(s);
     return st;
 }
@@ -957,7 +985,7 @@ int surfdisp_oracle_forward_batch(int B, int Lmax, const int *nlay, const float 
 #endif
     {
         ctx_t *s = (ctx_t *)malloc(sizeof(ctx_t));
-        if (s) s->tr_c = NULL;
+        if (s) { s->tr_c = NULL; s->c_at = NULL; }
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 16)
 #endif

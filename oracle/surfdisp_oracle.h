@@ -39,6 +39,13 @@ int surfdisp_oracle_forward_dbg(int nlay, int kind,
                                 const float *per, int nper,
                                 float *c_out, float *u_out, float *ratio_out);
 
+/* test hook: group velocity (and ellipticity) evaluated at given phase velocities c_at[nper] (see the .c file) */
+int surfdisp_oracle_forward_at(int nlay, int kind,
+                               const float *vp, const float *vs, const float *rho,
+                               const float *h, const float *qsinv,
+                               const float *per, int nper, const float *c_at,
+                               float *c_out, float *u_out);
+
 /* Same signature as the reference's Fortran symbol fast_surf_ (fast_surf.f:2-5). */
 void surfdisp_oracle_fast_surf_(const int *n_layer, const int *kind,
                                 const float *vp, const float *vs, const float *rho,

@@ -753,24 +753,25 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         const bool had_ell = OVERLAP && ell_pend && (st == ST_SCAN);
 
         bool solved = false, failed = false;
-        // A secular function that left the fp32 range (NaN: products of e^{k d} terms beyond 3e38 in
-        // very thick layers at short periods).  The reference's scan compares SIGN(1., del): the NaNs
-        // its arithmetic produces carry the sign bit (x86 default NaN) and both secular functions
-        // return the NEGATED recursion result (surfa.f:179,357), so a NaN passes as a positive value
-        // (negnan above); once a NaN is an end of the bracket it poisons NEVILL's interpolation,
-        // the 50-cycle limit trips and the whole call returns nothing (surfa.f:17-27 ->
-        // calcul.f:172-189 -> 9999).  Same here: a bracket with a NaN end, or a NaN refine point,
-        // fails the stack.
-        const bool nan_bracket = (st == ST_SCAN) && !(fastok && coarse) && (fl >= 0) && e_cross && ((e_d != e_d) || (e_pd != e_pd));
-        const bool nan_refine = (st == ST_REFINE) && ((__ballot(eval && (val != val)) & tmask) != 0ull);
-        const bool fatal = nan_bracket || nan_refine;
+        // A secular function that left the fp32 range (NaN / inf: products of e^{k d} terms beyond 3e38 in very
+        // thick layers at short periods).  The reference's scan compares SIGN(1., del): the NaNs its arithmetic
+        // produces carry the sign bit (x86 default NaN) and both secular functions return the NEGATED recursion
+        // result (surfa.f:179,357), so a NaN passes as a positive value (negnan above).  In NEVILL a NaN end value
+        // makes the Neville step return a NaN abscissa, and the arithmetic IFs of surfa.f:32-34 send a NaN to their
+        // third label, i.e. to a BISECTION step (flang and gfortran lower `if (x) l1,l2,l3` to x<0, x==0, else):
+        // the reference keeps halving on signs alone and returns the edge of the overflowed region as that
+        // period's root (pinned bit for bit in the oracle by tests/golden/ref_families.npz).  Same here: the
+        // subdivision below decides on signs with NaN = positive, and interpolation is only trusted on finite
+        // values (a non-finite estimate falls back to the bracket's low end once it is 1e-6 wide).
+        // What NEVILL cannot do is separate two fp32 numbers above 16 km/s (spacing 1.9e-6 > its 1e-6 tolerance,
+        // surfa.f:10,44): its 50-cycle limit trips (surfa.f:17-27), calcul.f:172-189 jumps to 9999 and the whole
+        // call returns nothing, also the periods already solved - SURFDISP_NUMERIC (see `fatal` in REFINE below).
+        bool fatal = false;
         if (OVERLAP && ell_pend && st == ST_SCAN) {
             if (j == 0) A.ratio[(size_t)ell_k * B + b] = 0.5f * v1 / v0;   // surfa.f:363
             ell_pend = false;
         }
-        if (fatal) {
-            nsolved = 0; k = 0; status = SURFDISP_NUMERIC; st = ST_DONE; ell_pend = false;
-        } else if (fastok && st == ST_SCAN && coarse) {
+        if (fastok && st == ST_SCAN && coarse) {
             ++passes;
             if (fl >= 0) {                                     // rescan this interval point by point
                 p0c = e_pc; p0d = e_pd; p0mm = e_pmm;
@@ -838,7 +839,8 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
                 ++passes;                                          // hard bound: fp32 cannot resolve <1 ulp
                 if (!(w > 1.0e-6f) || (!(w > A.wtol) && agree) || passes > 64) {
                     croot = p0c + (inside ? t : ts);
-                    if (croot <= W_B(mm_frozen - 1)) {             // calcul.f:191
+                    if (p0c >= 16.0f) fatal = true;                // NEVILL's 50 cycles, see above
+                    else if (croot <= W_B(mm_frozen - 1)) {        // calcul.f:191
                         if (want_ratio) {
                             if (OVERLAP && k + 1 < P) {
                                 // snapshot the layers the ellipticity recursion reads, then move on:
@@ -868,6 +870,9 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
 #ifdef SD_STATS
         { const unsigned long long m = __ballot(solved && j == 0); if (lane == 0 && m) atomicAdd(&g_stats[4], (unsigned long long)__popcll(m)); }
 #endif
+        if (fatal) {
+            nsolved = 0; k = 0; status = SURFDISP_NUMERIC; st = ST_DONE; ell_pend = false; solved = false; failed = false;
+        }
         if (solved) {
             if (j == 0) {
                 A.c[(size_t)k * B + b] = croot;                // period-major: coalesced across teams

@@ -29,9 +29,29 @@ def load_cases():
     return cases
 
 
+def load_families():
+    """tests/golden/ref_families.npz (one small fixture per soak family, tests/golden/make_golden_families.py)
+    -> {case: dict(model, nlay, periods, kind, c, u)}."""
+    z = np.load(os.path.join(GOLDEN, "ref_families.npz"))
+    cases = {}
+    for key in z.files:
+        case, field = key.split("/")
+        if case == "__meta__":
+            continue
+        cases.setdefault(case, {})[field] = z[key]
+    for d in cases.values():
+        d["kind"] = int(d["kind"])
+    return cases
+
+
 @pytest.fixture(scope="session")
 def ref_cases():
     return load_cases()
+
+
+@pytest.fixture(scope="session")
+def ref_families():
+    return load_families()
 
 
 @pytest.fixture(scope="session")

@@ -1,23 +1,35 @@
 """Parity tests proper: the HIP path (through the C ABI) against
   (a) the committed golden vectors captured from the reference Fortran, and
   (b) the CPU oracle on seeded inputs.
-Floating-point bar (BASELINE.json north_star): 1e-4 relative on c and U; the tests hold
-the tighter 2e-5 on c and 5e-5 on U that the kernels actually achieve on these stacks.
-Zero patterns (= the reference's failure convention) must coincide exactly.
+Floating-point bar (BASELINE.json north_star): 1e-4 relative on c and U.  Held here: c <= 2e-5 everywhere; U <= 5e-5 on
+every golden case except the rough (unsorted, low-velocity-zone) families, which are held to the 1e-4 bar itself -
+EVERY entry, apart from the entries listed in tests/golden/u_exceptions.json: (stack, period) pairs next to
+osculating modes at which the reference's own two builds (FMA contraction on / off) disagree with each other by
+more than 2e-5 or return NaN (tests/golden/make_golden_spread.py).  Measured on MI355X (scripts/parity_table.py,
+profiles/r02a/parity_table.txt): worst unlisted entry 7.5e-5, the listed ones <= 1.2e-4.
+Zero patterns (= the reference's failure convention) coincide exactly on every case and every team size.
 """
 import ctypes
+import json
+import os
 
 import numpy as np
 import pytest
 
-from conftest import relerr, load_cases
+from conftest import relerr, load_cases, GOLDEN
 
 pytestmark = pytest.mark.gpu
 
 TOL_C = 2e-5
-TOL_U = 5e-5
+TOL_U = 5e-5            # smooth / water / sparse cases
+TOL_U_BAR = 1e-4        # north_star's bar: rough cases, every entry not in u_exceptions.json
+TOL_U_LISTED = 5e-4     # listed entries (the reference's own builds differ there / one returns NaN)
 CASES = sorted(load_cases().keys())
 TEAMS = (1, 2, 4, 8, 16, 32, 64)
+with open(os.path.join(GOLDEN, "u_exceptions.json")) as _f:
+    U_EXCEPTIONS = {}
+    for _e in json.load(_f)["entries"]:
+        U_EXCEPTIONS.setdefault(_e["case"], []).append((_e["stack"], _e["period_index"]))
 
 
 @pytest.fixture(scope="module")
@@ -30,42 +42,41 @@ def hip():
 
 
 def _check_u(u, ref_u, case):
-    """U parity.  On the rough (unsorted, sigma=0.15) stacks a few (stack, period) entries sit next
-    to osculating modes where the REFERENCE's own U moves by >200x the relative change of c (its
-    FMA and non-FMA builds differ by 2.6e-5 in U for 1.2e-7 in c there, and one entry turns NaN):
-    hold those cases to 5e-5 on 99% of the entries and 5e-3 on the rest; everything else to 5e-5."""
+    """U parity, entry by entry (see the module docstring)."""
+    u = np.asarray(u, np.float64); ref_u = np.asarray(ref_u, np.float64)
     ok = ref_u != 0
     if not ok.any():
         return
-    e = np.abs(np.asarray(u, np.float64)[ok] / np.asarray(ref_u, np.float64)[ok] - 1.0)
-    if case.startswith("rough"):
-        assert np.quantile(e, 0.99) < TOL_U, np.quantile(e, 0.99)
-        assert e.max() < 5e-3, e.max()
-    else:
-        assert e.max() < TOL_U, e.max()
+    e = np.zeros_like(ref_u)
+    e[ok] = np.abs(u[ok] / ref_u[ok] - 1.0)
+    e = np.where(np.isfinite(e), e, np.inf)
+    listed = np.zeros_like(ok)
+    for b, k in U_EXCEPTIONS.get(case, ()):
+        listed[b, k] = True
+    tol = TOL_U_BAR if case.startswith("rough") else TOL_U
+    assert e[ok & ~listed].max() < tol, (case, e[ok & ~listed].max())
+    if (ok & listed).any():
+        assert e[ok & listed].max() < TOL_U_LISTED, (case, e[ok & listed].max())
 
 
-def _solved_pattern_ok(c, ref_c, case):
-    """Unsolved periods are zeros in both.  Rough stacks sit on bracketing knife edges
-    (a scan step landing within rounding of a root), so allow a stack to differ there only
-    if it is flagged in the golden data as a failing stack."""
-    same = (c > 0) == (ref_c > 0)
-    return same.all(axis=1)
+def _same_zero_pattern(c, ref_c):
+    """Unsolved periods are zeros in both: the reference's failure convention, stack by stack."""
+    return np.array_equal(np.asarray(c) > 0, np.asarray(ref_c) > 0)
 
 
 @pytest.mark.parametrize("case", CASES)
 def test_golden_cases_default_team(hip, ref_cases, case):
     d = ref_cases[case]
     c, u, st = hip.forward_batch(d["model"], d["periods"], d["kind"])
-    rows = _solved_pattern_ok(c, d["c"], case)
-    assert rows.mean() >= (0.9 if case.startswith("rough") else 1.0), f"zero pattern differs in {np.sum(~rows)} stacks"
-    assert relerr(c[rows], d["c"][rows]) < TOL_C
-    _check_u(u[rows], d["u"][rows], case)
-    assert np.array_equal(st[rows] == 0, np.all(d["c"][rows] > 0, axis=1))
+    assert _same_zero_pattern(c, d["c"])
+    assert relerr(c, d["c"]) < TOL_C
+    _check_u(u, d["u"], case)
+    assert np.array_equal(st == 0, np.all(d["c"] > 0, axis=1))
 
 
 @pytest.mark.parametrize("team", TEAMS)
-@pytest.mark.parametrize("case", ["synth_L10_R", "synth_L10_L", "synth_L64_R", "water_L9_R", "rough_L10_R"])
+@pytest.mark.parametrize("case", ["synth_L10_R", "synth_L10_L", "synth_L64_R", "water_L9_R", "rough_L10_R", "rough_L64_R",
+                                  "rough_thick_L22_R", "rough_thick_L12_L"])
 def test_every_team_size_matches_golden(hip, ref_cases, case, team):
     from pysurfinv_amd import _lib
     d = ref_cases[case]
@@ -74,10 +85,33 @@ def test_every_team_size_matches_golden(hip, ref_cases, case, team):
         c, u, st = hip.forward_batch(d["model"], d["periods"], d["kind"])
     finally:
         _lib.lib().surfdisp_set_team(0)
-    rows = _solved_pattern_ok(c, d["c"], case)
-    assert rows.mean() >= (0.9 if case.startswith("rough") else 1.0)
-    assert relerr(c[rows], d["c"][rows]) < TOL_C
-    _check_u(u[rows], d["u"][rows], case)
+    assert _same_zero_pattern(c, d["c"])
+    assert relerr(c, d["c"]) < TOL_C
+    _check_u(u, d["u"], case)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_group_velocity_equals_the_oracles_at_the_same_phase_velocity(hip, ref_cases, case):
+    """Separates the group-velocity arithmetic from the conditioning of U(c): the oracle's REIGEN / LEIGEN (and
+    ellipticity) evaluated at the phase velocities the HIP path found (oracle test hook surfdisp_oracle_forward_at)
+    against the HIP group velocities - 1e-5 everywhere (measured <= 6.5e-6), the listed ill-conditioned entries and
+    their like 1e-4 (the ellipticity, taken at that c by two different arithmetics, feeds U with a large factor
+    there: measured 5.5e-5 at one entry for teams of 4 and 8 lanes)."""
+    from oracle import cport
+    from pysurfinv_amd import _lib
+    d = ref_cases[case]
+    for team in (0, 4):
+        _lib.lib().surfdisp_set_team(team)
+        try:
+            c, u, st = hip.forward_batch(d["model"], d["periods"], d["kind"])
+        finally:
+            _lib.lib().surfdisp_set_team(0)
+        co, uo = cport.group_at(d["model"], d["periods"], d["kind"], c)
+        ok = (uo != 0) & np.isfinite(uo) & (u != 0)
+        if not ok.any():
+            continue
+        e = np.abs(u[ok].astype(np.float64) / uo[ok] - 1.0)
+        assert np.quantile(e, 0.995) < 1e-5 and e.max() < 1e-4, (case, team, e.max())
 
 
 @pytest.mark.parametrize("wave", ["R", "L"])
@@ -203,14 +237,13 @@ def test_full_size_properties_config2(hip):
     assert relerr(c[idx], co) < TOL_C and relerr(u[idx], uo) < TOL_U
 
 
-def test_extreme_velocities_terminate(hip):
-    """Stacks far outside seismology.  Vs x 3 (roots up to ~14 km/s) must agree with the oracle.
-    Vs x 6 puts the roots above 16 km/s where one fp32 ulp (1.9e-6) exceeds NEVILL's 1e-6 bracket
-    tolerance, so the REFERENCE never converges there (50 cycles, LSTOP, all zeros; oracle status 3);
-    the HIP path has a pass bound instead and returns the root: it must terminate with finite
-    positive velocities (documented difference)."""
+def test_extreme_velocities_follow_the_reference(hip):
+    """Stacks far outside seismology.  Vs x 3 (roots up to ~14 km/s) must agree with the oracle.  Vs x 6 puts the
+    roots above 16 km/s, where one fp32 ulp (1.9e-6) exceeds NEVILL's 1e-6 bracket tolerance: the REFERENCE never
+    converges there (50 cycles, LSTOP, calcul.f:172-189 -> 9999: nothing is returned; oracle status 3).  The HIP
+    path reports exactly those stacks as SURFDISP_NUMERIC with all-zero outputs."""
     from oracle import cport
-    from pysurfinv_amd import synth
+    from pysurfinv_amd import synth, _lib
     per = synth.default_periods(12)
     model = synth.synth_models(64, 8, seed=9)
     model[:, 0:2] *= 3.0
@@ -219,8 +252,15 @@ def test_extreme_velocities_terminate(hip):
     assert np.array_equal(c > 0, co > 0)
     assert relerr(c, co) < 2e-5 and relerr(u, uo) < 1e-4
     model[:, 0:2] *= 2.0
-    c, u, st = hip.forward_batch(model, per, 2)
-    assert (st == 0).all() and np.isfinite(c).all() and (c > 16).all() and np.isfinite(u).all()
+    for team in (0, 1, 4, 64):
+        _lib.lib().surfdisp_set_team(team)
+        try:
+            c, u, st = hip.forward_batch(model, per, 2)
+        finally:
+            _lib.lib().surfdisp_set_team(0)
+        co, uo, so = cport.forward_batch(model, per, 2, nthreads=8)
+        assert (so == cport.NEVILL).all() and not co.any()
+        assert (st == _lib.NUMERIC).all() and not c.any() and not u.any()
 
 
 def test_sensitivity_kernels_match_oracle_finite_differences(hip, eus):
@@ -377,25 +417,95 @@ def test_independent_mode_failure_cascade_and_water(hip, ref_cases):
     assert np.isfinite(c).all() and c.shape == d["c"].shape
 
 
-def test_fp32_overflow_fails_the_stack_like_the_reference(hip):
-    """Two 200 km layers at T = 5 s: the secular function overflows fp32 (NaN).  The reference's NEVILL
-    then exhausts its 50 cycles and the whole call returns nothing - also the periods that could be
-    solved (calcul.f:172-189).  The HIP path reports SURFDISP_NUMERIC and zeros; neighbours in the
-    same batch are unaffected."""
+def test_fp32_overflow_regime_follows_the_reference(hip):
+    """Two 200 km layers at T = 5 s: the un-normalised secular function overflows fp32 (NaN / inf) below ~3.0 km/s.
+    The reference's scan treats a NaN as positive, brackets the edge of the overflowed region, and NEVILL - whose
+    arithmetic IFs send a NaN abscissa to a bisection step (surfa.f:32-34) - converges onto that edge: the first
+    period gets a spurious root (and a NaN group velocity), the later periods are solved normally.  The HIP path
+    does the same, for every team size; neighbours in the same batch are unaffected."""
     from oracle import cport
     from pysurfinv_amd import synth, _lib
     m = synth.synth_models(64, 2, seed=2, noise=0.05, monotone=False, total_thickness=400.0)
     ok = synth.synth_models(64, 2, seed=3, noise=0.1, monotone=True, total_thickness=60.0)
     model = np.concatenate([m, ok]).astype(np.float32)
     per = np.linspace(5, 100, 24).astype(np.float32)
+    co, uo, so = cport.forward_batch(model, per, 2, nthreads=8)
+    assert (so == 0).all() and (co > 0).all() and np.isnan(uo[:64, 0]).all()     # what the reference returns
     for team in (0, 1, 4, 64):
         assert _lib.lib().surfdisp_set_team(team) == 0
-        c, u, st = hip.forward_batch(model, per, 2)
-        co, uo, so = cport.forward_batch(model, per, 2, nthreads=8)
-        assert (so[:64] == 3).all() and not co[:64].any()            # oracle: NEVILL failure, no output
-        assert (st[:64] == _lib.NUMERIC).all() and not c[:64].any() and not u[:64].any()
-        assert (st[64:] == 0).all() and relerr(c[64:], co[64:]) < 2e-5 and relerr(u[64:], uo[64:]) < 1e-4
-    _lib.lib().surfdisp_set_team(0)
+        try:
+            c, u, st = hip.forward_batch(model, per, 2)
+        finally:
+            _lib.lib().surfdisp_set_team(0)
+        assert (st == 0).all() and (c > 0).all()
+        assert relerr(c, co) < 2e-5                                   # also the spurious first-period root
+        assert relerr(c[:, 1:], co[:, 1:]) < 2e-5 and relerr(u[:, 1:], uo[:, 1:]) < 1e-4
+        assert relerr(u[64:], uo[64:]) < 1e-4
+
+
+FAMILY_BARS = {
+    # family: (stacks that may differ in zero pattern or root choice, c tolerance, quantile of U held to 1e-4)
+    "sediment_R": (0, 1e-4, 0.985), "sediment_L": (0, 2e-5, 1.0),
+    "ragged_R": (0, 2e-5, 0.995), "ragged_L": (0, 2e-5, 1.0),
+    "overflow_R": (0, 2e-5, 0.985),
+    # one 2-layer stack (200 km over a half space, 3 and 6.4 s): three Love modes inside one 0.01 km/s bracket; which
+    # of them NEVILL lands on depends on its evaluation sequence, teams of >= 2 lanes return the lowest (DESIGN.md)
+    "overflow_L": (1, 2e-5, 1.0),
+}
+
+
+@pytest.mark.parametrize("family", sorted(FAMILY_BARS))
+def test_soak_family_fixtures(hip, ref_families, family):
+    """One small fixture per family of the builder-run differential soaks (tests/golden/make_golden_families.py:
+    what the reference Fortran returns for soft sediments at short periods, rough ragged stacks, the fp32-overflow
+    regime).  Zero patterns and root choice as the reference's (bar the listed stack), c within tolerance, the group
+    velocity equal to the oracle's AT THE SAME phase velocity, and within 1e-4 of the reference's own on all but the
+    ill-conditioned entries - where the reference's FMA and non-FMA builds differ from each other by up to 4.8e-4
+    (sediment_R) and 2.8e-3 (overflow_R); measured figures in profiles/r02a/parity_table.txt."""
+    from oracle import cport
+    from pysurfinv_amd import _lib
+    d = ref_families[family]
+    nbad_max, tol_c, q_u = FAMILY_BARS[family]
+    for team in (0, 1, 4, 16):
+        _lib.lib().surfdisp_set_team(team)
+        try:
+            c, u, st = hip.forward_batch(d["model"], d["periods"], d["kind"], nlay=d["nlay"])
+        finally:
+            _lib.lib().surfdisp_set_team(0)
+        same = (c > 0) == (d["c"] > 0)
+        with np.errstate(all="ignore"):
+            ec = np.where(d["c"] > 0, np.abs(c.astype(np.float64) / d["c"] - 1), 0.0)
+        good = same.all(axis=1) & (ec.max(axis=1) < tol_c)
+        assert (~good).sum() <= nbad_max, (family, team, int((~good).sum()))
+        co, uo = cport.group_at(d["model"][good], d["periods"], d["kind"], c[good], nlay=d["nlay"][good])
+        ok = np.isfinite(uo) & (np.abs(uo) > 1e-3) & (c[good] > 0)
+        e_same_c = np.abs(u[good][ok].astype(np.float64) / uo[ok] - 1)
+        assert np.isfinite(u[good][ok]).all() and np.quantile(e_same_c, 0.99) < 1e-4, (family, team, e_same_c.max())
+        ok = np.isfinite(d["u"][good]) & (np.abs(d["u"][good]) > 1e-3) & (c[good] > 0)
+        e = np.abs(u[good][ok].astype(np.float64) / d["u"][good][ok] - 1)
+        assert np.quantile(e, q_u) < 1e-4, (family, team, np.quantile(e, q_u))
+
+
+@pytest.mark.parametrize("wave", ["R", "L"])
+def test_wild_family_terminates_and_mostly_agrees(hip, ref_families, wave):
+    """Anything monotone: layers of 0.1-5 km/s, 10 m - 50 km thick, periods 0.1-300 s.  Kilometres of 0.1 km/s material
+    at 0.15 s are hundreds of wavelengths: the fp32 secular function is noise or NaN over most of the scan, both
+    implementations bracket rounding-decided sign changes, and which one comes first differs (the reference's own
+    U is NaN at a fifth of these entries).  What must hold: termination, finite-or-zero phase velocities, the
+    failure cascade (zeros only at the tail), and agreement on the well-posed majority."""
+    d = ref_families[f"wild_{wave}"]
+    c, u, st = hip.forward_batch(d["model"], d["periods"], d["kind"], nlay=d["nlay"])
+    assert np.isfinite(c).all() and (c >= 0).all()
+    nz = c > 0
+    assert (nz[:, :-1] | ~nz[:, 1:]).all()                       # once a period failed, all later ones are zero
+    both = nz & (d["c"] > 0)
+    e = np.abs(c[both].astype(np.float64) / d["c"][both] - 1)
+    # measured (profiles/r02a/parity_table.txt): Rayleigh median 9e-7, 79 % of the entries within 1e-4 (94 % at T >= 3 s);
+    # Love 49 % - its modes crowd far below the 0.01 km/s walk in the slow layers, brackets hold several roots, and
+    # an early period that lands on another overtone hands a different start value to every later one
+    assert (e < 1e-4).mean() > (0.7 if wave == "R" else 0.4)
+    if wave == "R":
+        assert np.median(e) < 1e-5
 
 
 @pytest.mark.parametrize("team", [2, 4, 8, 64])

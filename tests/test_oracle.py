@@ -106,3 +106,54 @@ def test_scan_trace_brackets_the_oracle_root(ref_cases):
         assert n - (first + 2) == 8                                # eight points recorded past the bracket
         assert ct[first] <= c_ref[k] <= ct[first + 1]
         assert np.all((mt[:n] >= 2) & (mt[:n] <= m.shape[1]))
+
+
+def test_group_at_hook_reproduces_the_oracles_own_group_velocities(ref_cases):
+    """surfdisp_oracle_forward_at with the oracle's own roots = the plain oracle, bit for bit; with a phase velocity
+    one ulp off, U moves (that is what the hook is for)."""
+    from oracle import cport
+    for name in ("synth_L10_R", "synth_L10_L", "rough_L64_R", "water_L9_R"):
+        d = ref_cases[name]
+        c0, u0, _ = cport.forward_batch(d["model"], d["periods"], d["kind"])
+        c1, u1 = cport.group_at(d["model"], d["periods"], d["kind"], c0)
+        assert np.array_equal(c0, c1) and np.array_equal(u0, u1, equal_nan=True), name
+        c2, u2 = cport.group_at(d["model"], d["periods"], d["kind"], np.nextafter(c0, np.float32(10)))
+        assert np.array_equal(c0, c2) and not np.array_equal(u0, u2, equal_nan=True), name
+
+
+def test_exception_list_is_what_the_spread_fixture_says(ref_cases):
+    """tests/golden/u_exceptions.json lists exactly the entries at which the reference's own two builds
+    (ref_cases.npz vs ref_spread.npz, tests/golden/make_golden_spread.py) differ by > 2e-5 in U or return NaN;
+    their zero patterns and phase velocities agree (<= 2e-6) everywhere."""
+    import json
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "ref_spread.npz"))
+    listed = {(e["case"], e["stack"], e["period_index"]) for e in json.load(open(os.path.join(GOLDEN, "u_exceptions.json")))["entries"]}
+    found = set()
+    for name, d in ref_cases.items():
+        c, u = z[f"{name}/c_fma"], z[f"{name}/u_fma"]
+        assert np.array_equal(c > 0, d["c"] > 0)
+        ok = d["c"] > 0
+        if not ok.any():
+            continue
+        assert np.abs(c[ok].astype(np.float64) / d["c"][ok] - 1).max() < 2e-6
+        with np.errstate(invalid="ignore"):
+            su = np.abs(u.astype(np.float64) / np.where(ok, d["u"], 1) - 1)
+        for b, k in zip(*np.where(ok & ~(su <= 2e-5))):
+            found.add((name, int(b), int(k)))
+    assert found == listed and len(listed) <= 4
+
+
+@pytest.mark.parametrize("family", ["sediment_R", "sediment_L", "wild_R", "wild_L", "overflow_R", "overflow_L",
+                                    "ragged_R", "ragged_L"])
+def test_oracle_bit_exact_on_soak_family_fixtures(ref_families, family):
+    """The C restatement against what the reference Fortran returned for the soak families
+    (tests/golden/make_golden_families.py) - bit for bit, NaN for NaN.  overflow_* and wild_* pin the NaN semantics:
+    the scan's SIGN(1., NaN) and NEVILL's arithmetic IFs (a NaN Neville abscissa takes the third label = a
+    bisection step, surfa.f:32-34), which is why the reference returns roots - not failures - next to the
+    overflowed region."""
+    from oracle import cport
+    d = ref_families[family]
+    c, u, st = cport.forward_batch(d["model"], d["periods"], d["kind"], nlay=d["nlay"], nthreads=4)
+    assert np.array_equal(c, d["c"]) and np.array_equal(u, d["u"], equal_nan=True)
