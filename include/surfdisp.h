@@ -170,6 +170,15 @@ int surfdisp_params_to_model_thermal_device(void *stream, int C, int N, int L, c
                                             const int *idesc, const double *fdesc,
                                             void *scratch, size_t scratch_bytes, float *model);
 
+/* ---- (7) introspection of the two-tier root search.  The production kernel hands the stacks it cannot treat
+ *          faithfully to an exact fallback kernel that runs right behind it inside the same call: a secular
+ *          function that leaves the fp32 range (the reference's overflow points depend on how it forms its matrix
+ *          entries, surfa.f:289-330) and brackets with more than one visible sign change (which root NEVILL,
+ *          surfa.f:2-83, lands on depends on its evaluation sequence).  Returns in *count how many stacks (in
+ *          SURFDISP_INDEPENDENT mode: (stack, period) units) of the last solve on `workspace` took that path.
+ *          Waits for `stream`. */
+int surfdisp_workspace_fallback_count(void *stream, const void *workspace, int B, int Lmax, int P, int *count);
+
 /* ---- tuning / introspection ------------------------------------------------------------- */
 /* lanes of one wavefront that cooperate on one stack's root search (1,2,4,...,64); 0 = choose
  * from (B, Lmax).  Also settable through the environment variable SURFDISP_TEAM. */

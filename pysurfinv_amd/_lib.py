@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsurfdisp_hip.so")
+# SURFDISP_LIB_PATH: developer override to load an experimental build of the same library (A/B measurements)
+LIB_PATH = os.environ.get("SURFDISP_LIB_PATH") or os.path.join(_HERE, "lib", "libsurfdisp_hip.so")
 
 SUCCESS, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_WORKSPACE = 0, -1, -2, -3, -4
 OK, PARTIAL, NOROOT, BADMODEL, NUMERIC = 0, 1, 2, 4, 8
@@ -28,7 +29,7 @@ EXPORTS = (
     "surfdisp_forward_batch_device_events", "surfdisp_events_create", "surfdisp_events_destroy",
     "surfdisp_events_elapsed_ms", "surfdisp_params_to_model_device",
     "surfdisp_params_to_model_thermal_device", "surfdisp_thermal_scratch_bytes",
-    "surfdisp_forward_kernels_device", "surfdisp_set_team", "surfdisp_get_team",
+    "surfdisp_forward_kernels_device", "surfdisp_workspace_fallback_count", "surfdisp_set_team", "surfdisp_get_team",
     "surfdisp_device_count", "surfdisp_abi_version", "surfdisp_last_error",
     "surfdisp_kernel_name",
 )
@@ -97,6 +98,8 @@ def lib() -> ctypes.CDLL:
     L.surfdisp_params_to_model_thermal_device.restype = ctypes.c_int
     L.surfdisp_params_to_model_thermal_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp,
                                                           vp, ctypes.c_size_t, vp]
+    L.surfdisp_workspace_fallback_count.restype = ctypes.c_int
+    L.surfdisp_workspace_fallback_count.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip]
     L.surfdisp_set_team.restype = ctypes.c_int
     L.surfdisp_set_team.argtypes = [ctypes.c_int]
     L.surfdisp_get_team.restype = ctypes.c_int

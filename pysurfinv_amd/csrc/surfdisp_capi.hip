@@ -60,7 +60,8 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 struct Carve {
     float *mdl, *ratio, *ct, *ut;
     int *nl, *nsolved;
-    float *fsafe;
+    float *fsafe, *ovf;
+    int *fb_count, *fb_list;
     size_t total;
 };
 
@@ -76,6 +77,9 @@ Carve carve(void *base, int B, int Lmax, int P)
     c.nl = reinterpret_cast<int *>(p + off);        off += align_up((size_t)B * sizeof(int));
     c.nsolved = reinterpret_cast<int *>(p + off);   off += align_up((size_t)B * sizeof(int));
     c.fsafe = reinterpret_cast<float *>(p + off);   off += align_up((size_t)B * sizeof(float));
+    c.ovf = reinterpret_cast<float *>(p + off);     off += align_up((size_t)3 * B * sizeof(float));
+    c.fb_count = reinterpret_cast<int *>(p + off);  off += align_up(sizeof(int));
+    c.fb_list = reinterpret_cast<int *>(p + off);   off += align_up((size_t)P * B * sizeof(int));
     c.total = off;
     return c;
 }
@@ -176,6 +180,18 @@ size_t surfdisp_workspace_bytes(int B, int Lmax, int P)
     return carve(nullptr, B, Lmax, P).total;
 }
 
+// introspection: how many stacks (or (stack, period) units in independent mode) the last solve that used this
+// workspace handed to the exact fallback kernel.  Waits for `stream`.
+int surfdisp_workspace_fallback_count(void *stream, const void *workspace, int B, int Lmax, int P, int *count)
+{
+    if (!workspace || !count || B < 1 || Lmax < 2 || P < 1) { set_err("bad argument"); return SURFDISP_ERR_INVALID; }
+    const Carve w = carve(const_cast<void *>(workspace), B, Lmax, P);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SD_HIP(hipMemcpyAsync(count, w.fb_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    SD_HIP(hipStreamSynchronize(s));
+    return SURFDISP_SUCCESS;
+}
+
 static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
                                const float *model, int P, const float *per, int kind,
                                float *c, float *u, int *status,
@@ -203,14 +219,18 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     const long units = (indep ? (long)B * P : (long)B) * (pipelined ? 2 : 1);
     const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax, kind == SURFDISP_KIND_RAYLEIGH && !phase_only);
 
-    sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl, P, indep ? w.nsolved : nullptr, w.fsafe};
+    sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl, P, indep ? w.nsolved : nullptr, w.fsafe, w.ovf, w.fb_count};
     if (ev) SD_HIP(hipEventRecord(ev[0], s));
     SD_HIP(sd::launch_prep(s, kind, pa));
     if (ev) SD_HIP(hipEventRecord(ev[1], s));
     const float wtol = kn.refine_wtol, atol = kn.refine_atol, phimax = kn.phimax;
     sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, phase_only ? nullptr : w.ratio, w.nsolved, status, wtol, atol,
-                     fastscan ? 1 : 0, w.fsafe, (!phase_only && use_overlap(Lmax, G)) ? 1 : 0, phimax};
+                     fastscan ? 1 : 0, w.fsafe, (!phase_only && use_overlap(Lmax, G)) ? 1 : 0, phimax,
+                     w.ovf, w.fb_count, w.fb_list};
     SD_HIP(sd::launch_phase(s, kind, G, indep, ph));
+    // the exact fallback re-solves what the production kernel listed (normally nothing: idle blocks exit at once)
+    ph.overlap = 0; ph.fast = 0;
+    SD_HIP(sd::launch_phase_exact(s, kind, indep, ph));
     if (ev) SD_HIP(hipEventRecord(ev[2], s));
     sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, g_dbg.load(std::memory_order_relaxed), kb, ka, kr};
     if (!phase_only) SD_HIP(sd::launch_group(s, kind, ga));

@@ -17,6 +17,8 @@ struct PrepArgs {
     int *nsolved_init;    // nullptr, or [B]: set to P (independent mode reduces it with atomicMin)
     float *fsafe;         // [B]: thickest layer (km) of a stack whose Vs and Vp never decrease with depth,
                           // 1e30 otherwise (the scan then skips nothing on that stack)
+    float *ovf;           // [3][B]: thickest flattened layer, 2 ln(max rho), 4 ln(2 max Vs^2): entry_overflow_risk
+    int *fb_count;        // [1]: zeroed here; stacks the production root search hands to the exact fallback
 };
 
 struct PhaseArgs {
@@ -34,6 +36,9 @@ struct PhaseArgs {
     const float *fsafe;   // [B], see PrepArgs
     int overlap;          // second LDS slot: the ellipticity passes ride in the next period's first scan pass
     float phimax;         // certified scan: largest vertical-phase increment (rad) of an interval that may be skipped
+    const float *ovf;     // [3][B], see PrepArgs
+    int *fb_count;        // [1] number of entries of fb_list
+    int *fb_list;         // [teams]: team indices (stack, or period * B + stack in independent mode) for the exact kernel
 };
 
 struct GroupArgs {
@@ -76,6 +81,9 @@ hipError_t launch_thermal(hipStream_t s, const LayersArgs &a);
 #define SD_PHASE_BLOCK 256
 #endif
 size_t phase_lds_bytes(int Lmax, int G, bool overlap);   // per workgroup of SD_PHASE_BLOCK lanes
+size_t phase_exact_lds_bytes(int Lmax, int G);
+int phase_exact_team(int Lmax);                          // lanes per stack of the exact fallback kernel
+hipError_t launch_phase_exact(hipStream_t s, int kind, bool independent, const PhaseArgs &a);
 hipError_t launch_finish(hipStream_t s, const FinishArgs &a);
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a);
 hipError_t launch_phase(hipStream_t s, int kind, int G, bool independent, const PhaseArgs &a);

@@ -75,6 +75,7 @@ SD_HD inline void prep_stack(const PrepArgs &A, const int b)
     const float pwr = pwr_of(KIND);
     const float apw = powr32(R0, pwr);
     float hmax = 0.0f, vs_prev = 0.0f, vp_prev = 0.0f;
+    float hthick = 0.0f, rhomax = 0.0f, bmax = 0.0f;   // flattened: thickest layer, largest density and Vs
     bool mono = true;
     if (ok) {
         float hs = 0.0f;          // running thickness sum, fp32 in layer order (flat1.f:33-37)
@@ -104,6 +105,10 @@ SD_HD inline void prep_stack(const PrepArgs &A, const int b)
             }
             const float hsf = R0 / r_i;
             const float hsr = powr32(1.0f / hsf, pwr);
+            // 6 % on the velocities for the attenuation correction (1 + qs ln(1/T)/pi, calcul.f:122-126)
+            hthick = fmaxf(hthick, dfl);
+            rhomax = fmaxf(rhomax, rho * fmaxf(qqq, hsr));
+            bmax = fmaxf(bmax, 1.06f * vs * fmaxf(dif, hsf));
             const size_t o = (size_t)i * B + b;
             const size_t fs = (size_t)Lmax * B;
             mdl[F_VP * fs + o] = vp;   mdl[F_VS * fs + o] = vs;   mdl[F_RHO * fs + o] = rho;
@@ -115,6 +120,12 @@ SD_HD inline void prep_stack(const PrepArgs &A, const int b)
     }
     A.nl[b] = ok ? n : 0;          // 0 => BADMODEL: K1/K2 write zeros
     if (A.fsafe) A.fsafe[b] = (ok && mono) ? hmax : 1.0e30f;
+    if (A.ovf) {                                               // inputs of the phase kernel's entry_overflow_risk
+        A.ovf[b] = hthick;
+        A.ovf[(size_t)B + b] = 2.0f * logf(fmaxf(rhomax, 1.0e-30f));
+        A.ovf[2 * (size_t)B + b] = 4.0f * logf(fmaxf(2.0f * bmax * bmax, 1.0e-30f));
+    }
+    if (A.fb_count && b == 0) *A.fb_count = 0;                 // empty list of stacks for the exact fallback
     if (A.nsolved_init) A.nsolved_init[b] = ok ? A.P : 0;      // independent mode: reduced with atomicMin
 }
 
@@ -228,6 +239,10 @@ __device__ __forceinline__ void sincos_cw(float x, float *sn, float *cs)
 // (returns -bb1, surfa.f:357); start = 2/3 -> the two ellipticity passes (returns bb1, surfa.f:360-363).
 // Same formulas as the reference; divisions folded into three reciprocals per layer and the
 // c-independent 1/a^2, 1/b^2 taken from LDS.
+// FACT = true : the layer matrix is applied in factorised form (below) - the production root search;
+// FACT = false: the fifteen entries are formed and multiplied out exactly as the reference does (surfa.f:289-330),
+//               so that overflow to inf / NaN happens where the reference's does - the exact fallback kernel.
+template <bool FACT>
 __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap, const int S,
                                                 const int mmax, const float c, const float T,
                                                 const int start, float &phi)
@@ -307,6 +322,34 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             sinqr = sh * rcp_nr(rb);
             cosq = ch;
         }
+        float n1, n2, n3, n4, n5;
+        if constexpr (FACT) {
+        // Factorised application of the layer's compound matrix.  Its fifteen entries (surfa.f:289-320) are linear
+        // in the nine products (cosp, rsinp, sinpr) x (cosq, rsinq, sinqr); collecting the update by product
+        // instead of by matrix entry gives, exactly (algebraic identity, checked in fp64 to 3e-14),
+        //   h = (b2, b3, b4)/rhoc, h5 = b5/rhoc^2,  u1 = g^2 b1 + 2g h3 - h5,  u2 = g1^2 b1 + 2g1 h3 - h5,
+        //   E1 = rsinp (rsinq u1 + cosq h2) - cosp rsinq h4 + (1 - cosp cosq) u2,
+        //   E2 = sinpr (sinqr u2 - cosq h4) + cosp sinqr h2 + (1 - cosp cosq) u1,
+        //   b1' = b1 - E1 - E2,  b3' = rhoc (h3 + g E1 + g1 E2),  b5' = rhoc^2 (h5 + g^2 E1 + g1^2 E2),
+        //   b2' = rhoc (cosp (cosq h2 + rsinq u1) + sinpr (rsinq h4 + cosq u2)),
+        //   b4' = rhoc (rsinp (sinqr h2 - cosq u1) - cosp (sinqr u2 - cosq h4))
+        // in 46 instead of ~100 operations, with the same fp32 accuracy against an fp64 evaluation.
+        const float h2 = b2 * irhoc, h3 = b3 * irhoc, h4 = b4 * irhoc, h5 = (b5 * irhoc) * irhoc;
+        const float g2 = g * g, g12 = g1 * g1;
+        const float u1 = fmaf(g2, b1, fmaf(g + g, h3, -h5));
+        const float u2 = fmaf(g12, b1, fmaf(g1 + g1, h3, -h5));
+        const float D = fmaf(-cosp, cosq, 1.0f);
+        const float t1 = fmaf(rsinq, u1, cosq * h2);            // rsinq u1 + cosq h2
+        const float t2 = fmaf(sinqr, u2, -(cosq * h4));         // sinqr u2 - cosq h4
+        const float Cx = cosp * rsinq, Cy = cosp * sinqr;
+        const float E1 = fmaf(rsinp, t1, fmaf(-Cx, h4, D * u2));
+        const float E2 = fmaf(sinpr, t2, fmaf(Cy, h2, D * u1));
+        n1 = (b1 - E1) - E2;
+        n3 = rhoc * fmaf(g, E1, fmaf(g1, E2, h3));
+        n5 = (rhoc * rhoc) * fmaf(g2, E1, fmaf(g12, E2, h5));
+        n2 = rhoc * fmaf(cosp, t1, sinpr * fmaf(rsinq, h4, cosq * u2));
+        n4 = rhoc * fmaf(rsinp, fmaf(sinqr, h2, -(cosq * u1)), -(cosp * t2));
+        } else {
         // the fifteen distinct entries, surfa.f:289-320 (common factors g*rr, g1*ss and their multiples
         // computed once)
         const float rr = rsinp * rsinq, ss = sinpr * sinqr, cc = cosp * cosq;
@@ -337,11 +380,12 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         const float a42 = rsinp * sinqr;
         const float a51 = rhocs * (2.0f * gg1 * gg1c + g * Z + g1 * W);
         // compound-matrix product with its symmetries, surfa.f:326-330
-        const float n1 = a11 * b1 + a12 * b2 + a13 * b3 + a14 * b4 + a15 * b5;
-        const float n2 = a21 * b1 + a22 * b2 + a23 * b3 + a24 * b4 - a14 * b5;
-        const float n3 = a31 * b1 + a32 * b2 + a33 * b3 - 0.5f * a23 * b4 + 0.5f * a13 * b5;
-        const float n4 = a41 * b1 + a42 * b2 - 2.0f * a32 * b3 + a22 * b4 - a12 * b5;
-        const float n5 = a51 * b1 - a41 * b2 + 2.0f * a31 * b3 - a21 * b4 + a11 * b5;
+        n1 = a11 * b1 + a12 * b2 + a13 * b3 + a14 * b4 + a15 * b5;
+        n2 = a21 * b1 + a22 * b2 + a23 * b3 + a24 * b4 - a14 * b5;
+        n3 = a31 * b1 + a32 * b2 + a33 * b3 - 0.5f * a23 * b4 + 0.5f * a13 * b5;
+        n4 = a41 * b1 + a42 * b2 - 2.0f * a32 * b3 + a22 * b4 - a12 * b5;
+        n5 = a51 * b1 - a41 * b2 + 2.0f * a31 * b3 - a21 * b4 + a11 * b5;
+        }
         b1 = n1; b2 = n2; b3 = n3; b4 = n4; b5 = n5;
     };
     const int last = mmax - 1;                                       // the half space
@@ -474,9 +518,18 @@ enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3 };
 //   period, on a freshly built full stack.  P times more teams, P times shorter dependency chain:
 //   the mode for small batches; equal to the faithful mode to ~1e-6 on well-behaved (monotone)
 //   stacks, NOT on rough ones (defects 2 and 9) - the caller opts in.
-// FAST = true: certified coarse-to-fine scan, the default (instantiated for teams of 2, 4 and 8 lanes
-// only); FAST = false: every grid point (SURFDISP_EXACTSCAN, and all larger teams).
-template <int KIND, int G, bool INDEP, bool FAST = false>
+// FAST = true: opt-in heuristic coarse-to-fine scan (SURFDISP_FASTSCAN; instantiated for teams of 2, 4 and 8 lanes
+// only); FAST = false: every grid point, as the reference - the default, and all larger teams.
+// EXACT = false: the production root search - factorised Rayleigh recursion, team subdivision + interpolation
+//   instead of NEVILL.  A team that meets what those two cannot reproduce faithfully - a secular function that
+//   leaves the fp32 range (the reference's overflow points depend on how it forms its matrix entries) or a
+//   bracket with more than one visible sign change (which of several roots NEVILL lands on depends on its
+//   evaluation sequence) - appends its stack to A.fb_list and stops.
+// EXACT = true : the fallback that re-solves the listed stacks from their first period: the reference's own
+//   matrix-entry arithmetic (delta_rayleigh<false>) and a statement-by-statement NEVILL (surfa.f:2-83), one
+//   evaluation per pass, every lane of the team at the same trial velocity.  Rare by construction, so its speed
+//   does not matter; launched after the production kernel with a grid for the worst case, idle blocks exit.
+template <int KIND, int G, bool INDEP, bool FAST = false, bool EXACT = false>
 __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArgs A)
 {
     extern __shared__ float w_lds[];
@@ -489,18 +542,24 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
     const unsigned long long tmask =
         (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << tbase);
     const int Lcap = A.Lmax, B = A.B, P = A.P;
-    const long tg = (long)blockIdx.x * S + slot;           // team index
+    long tg = (long)blockIdx.x * S + slot;                 // team index
+    bool team_valid = INDEP ? (tg < (long)B * P) : (tg < B);
+    if (EXACT) {                                           // the units listed by the production kernel
+        team_valid = tg < (long)(*A.fb_count);
+        tg = team_valid ? (long)A.fb_list[tg] : 0;
+    }
     const int b = INDEP ? (int)(tg % B) : (int)tg;         // consecutive teams = consecutive stacks
     const int k_own = INDEP ? (int)(tg / B) : 0;           // INDEP: the one period this team solves
-    const bool team_valid = INDEP ? (tg < (long)B * P) : (tg < B);
     float *wq = w_lds + slot;
     // second slot: a snapshot of the layers the ellipticity recursion of period k still needs while
     // the main slot already holds period k+1 (only for teams of >= 4 lanes, see OVERLAP below)
     // the ellipticity (two more recursions per period, surfa.f:360-363) only feeds the group-velocity
     // kernel: a phase-only call (A.ratio == nullptr) skips it altogether
     const bool want_ratio = (KIND == 2) && (A.ratio != nullptr);
-    const bool OVERLAP = want_ratio && (G >= 4) && !INDEP && (A.overlap != 0);
+    const bool OVERLAP = !EXACT && want_ratio && (G >= 4) && !INDEP && (A.overlap != 0);
     float *wq2 = w_lds + (size_t)NFW * Lcap * S + slot;
+    // EXACT: NEVILL's interpolation table x(1..11), y(1..11) (surfa.f:8) of this team, behind the working stacks
+    float *nvx = w_lds + (size_t)NFW * Lcap * S + (size_t)slot * 24, *nvy = nvx + 12;
     const float *__restrict__ mdl = A.mdl;
     const size_t fs = (size_t)Lcap * B;
 
@@ -536,6 +595,9 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
     bool ell_pend = false;
     int ell_k = 0, ell_mm = 2;
     float ell_c = 1.0f, ell_T = 1.0f;
+    // EXACT: NEVILL's state between two evaluations (c1, del1 = p0c, p0d; c2, del2 = cb, db; c3 = croot)
+    int nv_nev = 1, nv_m = 1, nv_ic = 0;
+    bool defer = false;                // !EXACT: this stack goes to the exact fallback kernel
 
     // (re)build the working stack for period k over the first nflat layers only -- the reference
     // refreshes just the layers inside the previous period's effective half space and leaves the
@@ -566,6 +628,19 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
+    // Rayleigh, production kernel: can a matrix ENTRY of the reference overflow fp32 in this period although the
+    // factorised recursion stays finite?  The largest entry is a51 ~ rhoc^2 g^4 rsinp rsinq <= rhoc^2 g^4 e^(pm+qm)
+    // with pm + qm <= 2 k d.  Bound it per stack (thickest layer, largest rho and Vs: prep kernel) at the lowest
+    // trial velocity of the period; beyond e^84 the stack goes to the exact fallback.
+    auto entry_overflow_risk = [&](float c_lo) -> bool {
+        if (EXACT || KIND != 2 || !team_valid) return false;
+        const float hthick = A.ovf[b], lnrho2 = A.ovf[(size_t)B + b], lng4 = A.ovf[2 * (size_t)B + b];
+        const float c_hi = W_B(mm_carry - 1) + 0.31f;                      // upper guard of the scan, calcul.f:166
+        const float lnmag = 12.566371f * hthick / (c_lo * T) + lnrho2 + 4.0f * __logf(c_hi) +
+                            fmaxf(lng4 - 8.0f * __logf(c_lo), 0.0f);
+        return !(lnmag < 84.0f);                                           // also when c_lo or T is not positive
+    };
+
     if (st != ST_DONE) {
         T = A.per[k];
         // clear the slot (a new process sees zeroed COMMON /d/)
@@ -581,6 +656,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         p0c = qq * (1.0f + b_corr);
         if (water) p0c = 0.5f;
         first = true;
+        defer = entry_overflow_risk(p0c);
     }
 
     while (__any(st != ST_DONE)) {
@@ -606,6 +682,8 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
                 for (int i = 0; i < G; ++i) if (i < nadd) cj = cj + DC;
             }
             mmj = drop_layers(wq, Lcap, S, n, cj, T);          // idrop=0 before every scan trial
+        } else if (EXACT && st == ST_REFINE) {
+            cj = croot; mmj = mm_frozen;                       // NEVILL's c3, idrop = 1
         } else if (st == ST_REFINE) {
             const float w = cb - p0c;
             cj = p0c + (float)(j + 1) * (w / (float)(G + 1));
@@ -632,7 +710,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         }
         float val = 0.0f, phj = 0.0f;
         if (eval) {
-            if (KIND == 2) val = delta_rayleigh(wl, Lcap, S, mmj, cj, Tl, start, phj);
+            if (KIND == 2) val = delta_rayleigh<!EXACT>(wl, Lcap, S, mmj, cj, Tl, start, phj);
             else           val = delta_love(wl, Lcap, S, mmj, cj, Tl, phj);
         }
         // ---------------------------------------------------------------- team-level decisions
@@ -760,13 +838,19 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         // makes the Neville step return a NaN abscissa, and the arithmetic IFs of surfa.f:32-34 send a NaN to their
         // third label, i.e. to a BISECTION step (flang and gfortran lower `if (x) l1,l2,l3` to x<0, x==0, else):
         // the reference keeps halving on signs alone and returns the edge of the overflowed region as that
-        // period's root (pinned bit for bit in the oracle by tests/golden/ref_families.npz).  Same here: the
+        // period's root (pinned bit for bit by the fixtures tests/golden/ref_families.npz).  Same here: the
         // subdivision below decides on signs with NaN = positive, and interpolation is only trusted on finite
         // values (a non-finite estimate falls back to the bracket's low end once it is 1e-6 wide).
         // What NEVILL cannot do is separate two fp32 numbers above 16 km/s (spacing 1.9e-6 > its 1e-6 tolerance,
         // surfa.f:10,44): its 50-cycle limit trips (surfa.f:17-27), calcul.f:172-189 jumps to 9999 and the whole
         // call returns nothing, also the periods already solved - SURFDISP_NUMERIC (see `fatal` in REFINE below).
         bool fatal = false;
+        if (!EXACT) {
+            // what this kernel does not reproduce faithfully goes to the exact fallback (see the template flags)
+            const bool nonfin = ((__ballot(eval && !fin(val)) & tmask) != 0ull);
+            const int ncross = __popcll(__ballot(searching && cross) & tmask) + ((negnan(l_d) != negnan(db)) ? 1 : 0);
+            if (st != ST_DONE && (nonfin || (st == ST_REFINE && ncross >= 2))) defer = true;
+        }
         if (OVERLAP && ell_pend && st == ST_SCAN) {
             if (j == 0) A.ratio[(size_t)ell_k * B + b] = 0.5f * v1 / v0;   // surfa.f:363
             ell_pend = false;
@@ -794,6 +878,10 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
                 p0ok = (e_pmm == e_mm);
                 passes = 0;
                 st = ST_REFINE;
+                if (EXACT) {                                   // NEVILL's prologue, surfa.f:12-16
+                    nv_ic = 0; nv_nev = 1; nv_m = 1;
+                    croot = (p0c + cb) / 2.0f;                 // c3, evaluated by the next pass
+                }
             } else if (fl >= 0) {
                 failed = true;                                 // label 250
             } else {
@@ -804,6 +892,60 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
                     fine_left -= had_ell ? G - 2 : G;
                     if (fine_left <= 0 && fsafe <= 3.0f * p0c * T) { coarse = true; q0ok = false; }
                 }
+            }
+        } else if (EXACT && st == ST_REFINE) {
+            // NEVILL, statement by statement (surfa.f:17-83).  One evaluation per pass: del3 = Delta(c3) has just
+            // been computed by every lane of the team (v0); what follows runs up to the next evaluation.
+            // SIGN(1., x): the reference's NaNs are positive when they come out of the secular function (negnan
+            // above) or are passed on by a subtraction, negative when a subtraction creates them (inf - inf: the
+            // x86 default NaN).  No fused multiply-adds: the reference is built without contraction.
+#pragma clang fp contract(off)
+            auto sg = [](float x) { return (signbit(x) && !(x != x)) ? -1.0f : 1.0f; };
+            auto sgsub = [&](float a, float bq) {
+                const float r = a - bq;
+                if (r != r) return ((a != a) || (bq != bq)) ? 1.0f : -1.0f;
+                return signbit(r) ? -1.0f : 1.0f;
+            };
+            float c1 = p0c, c2 = cb, d1 = p0d, d2 = db, c3 = croot;
+            const float d3 = v0;
+            nv_ic = nv_ic + 1;
+            bool fin_ = false;
+            if (!(nv_ic < 50)) fatal = true;                   // TOO MANY CYCLES: lstop, calcul.f:172-189 -> 9999
+            else {
+                bool bis;
+                if (c1 - c3 <= 0.0f) bis = (c2 - c3 <= 0.0f);  // 777 / 1320 / 1330: arithmetic IFs, a NaN
+                else bis = !(c2 - c3 < 0.0f);                  // expression takes the third label
+                if (!bis) {
+                    const float s13s = sgsub(d1, d3), s32s = sgsub(d3, d2);            // label 1000
+                    if (sg(d3) * sg(d1) <= 0.0f) { c2 = c3; d2 = d3; } else { c1 = c3; d1 = d3; }
+                    if (fabsf(c1 - c2) - 0.1e-5f <= 0.0f) fin_ = true;                 // 1444: accur1
+                    else {
+                        if (s13s != s32s) nv_nev = 0;
+                        const float ss1 = fabsf(d1), s1 = 0.1f * ss1, ss2 = fabsf(d2), s2 = 0.1f * ss2;
+                        if (s1 > ss2 || s2 > ss1) bis = true;
+                        else if (nv_nev == 0) bis = true;
+                        else {
+                            int m = nv_m;
+                            if (nv_nev == 2) { nvx[m + 1] = c3; nvy[m + 1] = d3; }     // 1350
+                            else { nvx[1] = c1; nvy[1] = d1; nvx[2] = c2; nvy[2] = d2; m = 1; }
+                            const float ym1 = nvy[m + 1];
+                            for (int kk = 1; kk <= m; ++kk) {                           // 1355-1360
+                                const int jn = m - kk + 1;
+                                const float yj = nvy[jn];
+                                if (fabsf(ym1 - yj) <= 0.1e-7f) { bis = true; break; }
+                                nvx[jn] = (-yj * nvx[jn + 1] + ym1 * nvx[jn]) / (ym1 - yj);
+                            }
+                            if (!bis) { c3 = nvx[1]; nv_nev = 2; nv_m = (m + 1 > 10) ? 10 : m + 1; }   // 21
+                        }
+                    }
+                }
+                if (!fin_ && bis) { c3 = (c1 + c2) / 2.0f; nv_nev = 1; nv_m = 1; }      // 1344
+                p0c = c1; p0d = d1; cb = c2; db = d2; croot = c3;
+            }
+            if (fin_) {                                        // label 20: cc = c3
+                if (croot <= W_B(mm_frozen - 1)) {             // calcul.f:191
+                    if (want_ratio) { st = ST_ELLIP; sub = 0; } else solved = true;
+                } else failed = true;
             }
         } else if (st == ST_REFINE) {
             // new bracket + one more known point next to it (for the final 3-point step)
@@ -870,6 +1012,10 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
 #ifdef SD_STATS
         { const unsigned long long m = __ballot(solved && j == 0); if (lane == 0 && m) atomicAdd(&g_stats[4], (unsigned long long)__popcll(m)); }
 #endif
+        if (!EXACT && defer) {
+            if (j == 0) A.fb_list[atomicAdd(A.fb_count, 1)] = (int)tg;
+            defer = false; st = ST_DONE; ell_pend = false; solved = false; failed = false; fatal = false;
+        }
         if (fatal) {
             nsolved = 0; k = 0; status = SURFDISP_NUMERIC; st = ST_DONE; ell_pend = false; solved = false; failed = false;
         }
@@ -889,6 +1035,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
                 p0d = 0.0f; p0mm = 0; p0ok = false; first = true; passes = 0;
                 coarse = false; fine_left = 1; q0ok = false;
                 st = ST_SCAN;
+                defer = entry_overflow_risk(p0c);              // acted on at the end of the next pass
             }
         }
         if (failed) {
@@ -1585,12 +1732,12 @@ namespace {
 
 constexpr int SD_MAX_DEVICES = 64;
 
-template <int KIND, int G, bool INDEP, bool FAST = false>
+template <int KIND, int G, bool INDEP, bool FAST = false, bool EXACT = false>
 hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 {
     constexpr int S = SD_PHASE_BLOCK / G;
-    const size_t lds = sd::phase_lds_bytes(a.Lmax, G, a.overlap != 0);
-    auto kern = sd::surfdisp_phase_kernel<KIND, G, INDEP, FAST>;
+    const size_t lds = EXACT ? sd::phase_exact_lds_bytes(a.Lmax, G) : sd::phase_lds_bytes(a.Lmax, G, a.overlap != 0);
+    auto kern = sd::surfdisp_phase_kernel<KIND, G, INDEP, FAST, EXACT>;
     // raise the dynamic-LDS limit of this instantiation only when a launch needs more than any before it (per
     // device): the attribute call costs ~10 us, visible in launch-bound Metropolis loops
     static std::atomic<size_t> lds_set[SD_MAX_DEVICES];
@@ -1608,6 +1755,17 @@ hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
     const int grid = (int)((teams + S - 1) / S);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SD_PHASE_BLOCK), lds, s, a);
     return hipGetLastError();
+}
+
+// the exact fallback: teams of 16 lanes, or as many as it takes for the working stacks to fit 64 KB of LDS
+template <int KIND, bool INDEP>
+hipError_t launch_phase_x(hipStream_t s, const sd::PhaseArgs &a)
+{
+    switch (sd::phase_exact_team(a.Lmax)) {
+        case 16: return launch_phase_g<KIND, 16, INDEP, false, true>(s, a);
+        case 32: return launch_phase_g<KIND, 32, INDEP, false, true>(s, a);
+        default: return launch_phase_g<KIND, 64, INDEP, false, true>(s, a);
+    }
 }
 
 template <int KIND, bool INDEP>
@@ -1640,6 +1798,20 @@ namespace sd {
 // working stack per team (+ the ellipticity snapshot slot for teams of >= 4 lanes; allocated for
 // Love too so that one number describes a launch)
 size_t phase_lds_bytes(int Lmax, int G, bool overlap) { return (size_t)((G >= 4 && overlap) ? 2 : 1) * NFW * Lmax * (SD_PHASE_BLOCK / G) * sizeof(float); }
+// exact fallback: one working stack per team + NEVILL's table x(12), y(12)
+size_t phase_exact_lds_bytes(int Lmax, int G) { return (size_t)(NFW * Lmax + 24) * (SD_PHASE_BLOCK / G) * sizeof(float); }
+int phase_exact_team(int Lmax)
+{
+    int G = 16;
+    while (G < 64 && phase_exact_lds_bytes(Lmax, G) > 64u * 1024u) G *= 2;
+    return G;
+}
+
+hipError_t launch_phase_exact(hipStream_t s, int kind, bool independent, const PhaseArgs &a)
+{
+    if (independent) return kind == 2 ? launch_phase_x<2, true>(s, a) : launch_phase_x<1, true>(s, a);
+    return kind == 2 ? launch_phase_x<2, false>(s, a) : launch_phase_x<1, false>(s, a);
+}
 
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a)
 {

@@ -141,6 +141,16 @@ class BatchPlan:
         return self.c, self.u, self.status
 
 
+    def fallback_count(self):
+        """Stacks of the last ``run`` that the production root search handed to the exact fallback kernel
+        (``surfdisp_workspace_fallback_count``; synchronises the current stream)."""
+        n = ctypes.c_int(0)
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        with self.torch.cuda.device(self.device):
+            _lib.check(_lib.lib().surfdisp_workspace_fallback_count(ctypes.c_void_p(stream), ctypes.c_void_p(self.workspace.data_ptr()),
+                                                                    self.B, self.L, self.P, ctypes.byref(n)))
+        return int(n.value)
+
     def run_kernels(self, model, periods, kind=2, nlay=None, want_vp=True, want_rho=True):
         """Forward solve + analytic partial derivatives of the phase velocity
         (``surfdisp_forward_kernels_device``): returns (c, u, status, dcdb, dcda, dcdr) with the

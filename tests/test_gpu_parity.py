@@ -282,7 +282,7 @@ def test_sensitivity_kernels_match_oracle_finite_differences(hip, eus):
     # it inherits the c parity (~1e-6 km/s) amplified by 1/(0.2 H), in the reference just as here.
     # Compare the underlying differences, and the kernel itself where layers are thick enough.
     dd = (k["phv"] - kref) * 0.2 * H[None, :]
-    assert np.abs(dd).max() < 4e-6
+    assert np.abs(dd).max() < 1.2e-5          # = 6 units of c parity (TOL_C x 4 km/s = 8e-5 is the bar for ONE c)
     thick = H >= 10.0
     scale = np.abs(kref[:, thick]).max()
     assert np.abs(k["phv"][:, thick] - kref[:, thick]).max() < 2e-2 * scale
@@ -448,9 +448,9 @@ FAMILY_BARS = {
     "sediment_R": (0, 1e-4, 0.985), "sediment_L": (0, 2e-5, 1.0),
     "ragged_R": (0, 2e-5, 0.995), "ragged_L": (0, 2e-5, 1.0),
     "overflow_R": (0, 2e-5, 0.985),
-    # one 2-layer stack (200 km over a half space, 3 and 6.4 s): three Love modes inside one 0.01 km/s bracket; which
-    # of them NEVILL lands on depends on its evaluation sequence, teams of >= 2 lanes return the lowest
-    "overflow_L": (1, 2e-5, 1.0),
+    # (one 2-layer stack, 200 km over a half space at 3 and 6.4 s, has three Love modes inside one 0.01 km/s bracket:
+    # which of them NEVILL lands on depends on its evaluation sequence - reproduced by the exact fallback kernel)
+    "overflow_L": (0, 2e-5, 1.0),
 }
 
 
@@ -483,6 +483,7 @@ def test_soak_family_fixtures(hip, ref_families, family):
         assert np.isfinite(u[good][ok]).all() and np.quantile(e_same_c, 0.99) < 1e-4, (family, team, e_same_c.max())
         ok = np.isfinite(d["u"][good]) & (np.abs(d["u"][good]) > 1e-3) & (c[good] > 0)
         e = np.abs(u[good][ok].astype(np.float64) / d["u"][good][ok] - 1)
+        e = np.where(np.isfinite(e), e, np.inf)                  # a NaN of ours where the reference is finite counts
         assert np.quantile(e, q_u) < 1e-4, (family, team, np.quantile(e, q_u))
 
 
@@ -580,3 +581,22 @@ def test_pipelined_hint_changes_only_the_launch(hip, ref_cases):
     c1, u1, s1 = plan.run(model, per, kind=2, pipelined=True)
     assert torch.equal(s0, s1) and torch.equal(c0 > 0, c1 > 0)
     assert float((c1 / c0 - 1).abs().max()) < 4e-6 and float((u1 / u0 - 1).abs().max()) < 1e-5
+
+
+def test_exact_fallback_takes_only_what_it_must(hip, ref_families):
+    """Two-tier root search: the bench-like workload hands nothing to the exact fallback kernel; stacks whose
+    secular function leaves the fp32 range all go there (and come back with the reference's answers,
+    test_fp32_overflow_regime_follows_the_reference / test_soak_family_fixtures)."""
+    import torch
+    from pysurfinv_amd import synth, forward
+    per = torch.from_numpy(synth.default_periods(20)).cuda()
+    plan = forward.BatchPlan(4096, 10, 20)
+    plan.run(torch.from_numpy(synth.synth_models(4096, 10, seed=0)).cuda(), per, kind=2)
+    assert plan.fallback_count() == 0
+    plan.run(torch.from_numpy(synth.synth_models(4096, 10, seed=0)).cuda(), per, kind=1)
+    assert plan.fallback_count() == 0
+    d = ref_families["overflow_R"]
+    m = torch.from_numpy(np.ascontiguousarray(d["model"])).cuda()
+    plan = forward.BatchPlan(m.shape[0], m.shape[2], len(d["periods"]))
+    plan.run(m, torch.from_numpy(d["periods"]).cuda(), kind=2, nlay=torch.from_numpy(d["nlay"]).cuda())
+    assert plan.fallback_count() == m.shape[0]
