@@ -226,13 +226,21 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     const float wtol = kn.refine_wtol, atol = kn.refine_atol, phimax = kn.phimax;
     sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, phase_only ? nullptr : w.ratio, w.nsolved, status, wtol, atol,
                      fastscan ? 1 : 0, w.fsafe, (!phase_only && use_overlap(Lmax, G)) ? 1 : 0, phimax,
-                     w.ovf, w.fb_count, w.fb_list};
+                     w.ovf, w.fb_count, w.fb_list, pipelined ? 0 : 1};
+#ifdef SD_WAVECLOCK
+    ph.wclk = reinterpret_cast<unsigned long long *>(g_dbg.load(std::memory_order_relaxed));
+#endif
     SD_HIP(sd::launch_phase(s, kind, G, indep, ph));
     // the exact fallback re-solves what the production kernel listed (normally nothing: idle blocks exit at once)
     ph.overlap = 0; ph.fast = 0;
     SD_HIP(sd::launch_phase_exact(s, kind, indep, ph));
     if (ev) SD_HIP(hipEventRecord(ev[2], s));
-    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, g_dbg.load(std::memory_order_relaxed), kb, ka, kr};
+#ifdef SD_WAVECLOCK
+    double *gdbg = nullptr;                                // the debug buffer holds wavefront clocks in this build
+#else
+    double *gdbg = g_dbg.load(std::memory_order_relaxed);
+#endif
+    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, gdbg, kb, ka, kr};
     if (!phase_only) SD_HIP(sd::launch_group(s, kind, ga));
     sd::FinishArgs fa{B, P, w.ct, phase_only ? nullptr : w.ut, c, phase_only ? nullptr : u,
                       indep ? w.nsolved : nullptr, w.nl, status};

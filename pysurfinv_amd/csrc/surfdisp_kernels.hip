@@ -263,8 +263,18 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
     auto step = [&](const Lyr &y) {
         const float sv = y.sv, rho = y.rho, d = y.d, ia2 = y.ia2, ib2 = y.ib2, irho = y.ir;
         const float arga = fmaf(-csq, ia2, 1.0f);                    // 1 - c^2/a^2, surfa.f:211
-        float ra = sqrt_hw(fabsf(arga));
-        if (arga > 0.0f) ra = -ra;
+        // production kernel: ra and 1/ra from ONE v_rsq_f32 (1 ulp; ra = x rsq(x) to ~1.5 ulp) instead of
+        // v_sqrt_f32 + v_rcp_f32 + a Newton step - two quarter-rate instructions fewer per layer and wave type
+        float ra, ira = 0.0f;
+        if constexpr (FACT) {
+            const float xa = fabsf(arga), ya = __builtin_amdgcn_rsqf(xa);
+            ra = (xa > 0.0f) ? xa * ya : 0.0f;
+            ira = ya;
+            if (arga > 0.0f) { ra = -ra; ira = -ira; }
+        } else {
+            ra = sqrt_hw(fabsf(arga));
+            if (arga > 0.0f) ra = -ra;
+        }
         const float wd = wvno * d;
         const float rhoc = rho * csq;
         if (!(fabsf(sv) > ACCUR)) {
@@ -290,8 +300,16 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             return;
         }
         const float argb = fmaf(-csq, ib2, 1.0f);
-        float rb = sqrt_hw(fabsf(argb));
-        if (argb > 0.0f) rb = -rb;
+        float rb, irb = 0.0f;
+        if constexpr (FACT) {
+            const float xb = fabsf(argb), yb = __builtin_amdgcn_rsqf(xb);
+            rb = (xb > 0.0f) ? xb * yb : 0.0f;
+            irb = yb;
+            if (argb > 0.0f) { rb = -rb; irb = -irb; }
+        } else {
+            rb = sqrt_hw(fabsf(argb));
+            if (argb > 0.0f) rb = -rb;
+        }
         const float g = 2.0f * (sv * sv) * icsq;
         const float g1 = g - 1.0f;
         const float irhoc = irho * icsq;
@@ -301,25 +319,25 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         if (ra < 0.0f) {                                   // evanescent P, surfa.f:267-269
             float sh, ch; sinhcosh_sp(pm, &sh, &ch);
             rsinp = -ra * sh;
-            sinpr = sh * rcp_nr(ra);
+            sinpr = sh * (FACT ? ira : rcp_nr(ra));
             cosp = ch;
         } else if (ra == 0.0f) {
             rsinp = 0.0f; sinpr = wd; cosp = 1.0f;
         } else {                                           // oscillatory P, surfa.f:271-273
             float sn, cs; sincos_cw(pm, &sn, &cs);
-            rsinp = ra * sn; sinpr = sn * rcp_nr(ra); cosp = cs;
+            rsinp = ra * sn; sinpr = sn * (FACT ? ira : rcp_nr(ra)); cosp = cs;
             phi += pm;
         }
         if (fabsf(rb) < ACCUR) {
             rsinq = 0.0f; sinqr = wd; cosq = 1.0f;
         } else if (rb > 0.0f) {
             float sn, cs; sincos_cw(qm, &sn, &cs);
-            rsinq = rb * sn; sinqr = sn * rcp_nr(rb); cosq = cs;
+            rsinq = rb * sn; sinqr = sn * (FACT ? irb : rcp_nr(rb)); cosq = cs;
             phi += qm;
         } else {
             float sh, ch; sinhcosh_sp(qm, &sh, &ch);
             rsinq = -rb * sh;
-            sinqr = sh * rcp_nr(rb);
+            sinqr = sh * (FACT ? irb : rcp_nr(rb));
             cosq = ch;
         }
         float n1, n2, n3, n4, n5;
@@ -535,6 +553,9 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
     extern __shared__ float w_lds[];
     constexpr int S = SD_PHASE_BLOCK / G;                 // stacks (teams) per workgroup
     const int tid = threadIdx.x;
+#ifdef SD_WAVECLOCK
+    const unsigned long long wclk0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = tid & 63;
     const int slot = tid / G;
     const int j = tid % G;                     // lane index inside the team
@@ -659,7 +680,24 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         defer = entry_overflow_risk(p0c);
     }
 
+    int wprio = -1;
     while (__any(st != ST_DONE)) {
+        // The SIMD arbitrates between its wavefronts by priority, then age: left alone, the four wavefronts of a
+        // SIMD finish one after the other and the last one runs alone for a seventh of the kernel.  Let a wavefront
+        // that is behind (period index of its first team) go first: 2.39 -> 2.15 ms for one bench batch (profiles/r02c).
+        // Not when the caller keeps a second batch in flight (SURFDISP_PIPELINED): there the age order is what lets
+        // the older batch drain while the younger one fills the machine.
+        if (!INDEP && A.balance) {
+            const int kw = __builtin_amdgcn_readfirstlane(k);
+            const int pr = 3 - min(3, (4 * kw) / max(P, 1));
+            if (pr != wprio) {
+                wprio = pr;
+                if (pr == 3) __builtin_amdgcn_s_setprio(3);
+                else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+                else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+        }
         // ---------------------------------------------------------------- choose the trial point
         float cj = 1.0f;
         int mmj = 2, start = 1;
@@ -1043,6 +1081,12 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
             st = ST_DONE;
         }
     }
+#ifdef SD_WAVECLOCK
+    if (!EXACT && A.wclk && (threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * (SD_PHASE_BLOCK / 64) + (threadIdx.x >> 6);
+        A.wclk[2 * w] = wclk0; A.wclk[2 * w + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if (INDEP) {
         // a failed period zeroes itself and every later one (calcul.f:203-219): the first failing
         // period index is reduced over the stack's teams; the finish kernel applies it

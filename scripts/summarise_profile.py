@@ -20,15 +20,16 @@ SIMDS = 1024
 
 
 def short(name):
-    """Kernel family of a trace/counter row.  Kept out of the summary: the SURFDISP_EXACTSCAN root search
-    (last template argument false; the default, certified scan is <..., true>) and the group kernel with
-    analytic partials (last template argument true)."""
+    """Kernel family of a trace/counter row.  Template arguments of the root search: <KIND, G, INDEP, FAST, EXACT>.
+    Kept out of the summary: its opt-in fast-scan instantiation (FAST = true; bench.py times it beside the
+    headline), the exact fallback kernel (EXACT = true: launched behind every root search, normally idle) and the
+    group kernel with analytic partials (last template argument true)."""
     for k in KERNELS:
         if k in name:
-            targs = name.split("<")[-1].split(">")[0].replace(" ", "")
-            if k == "surfdisp_phase_kernel" and targs.endswith("false"):
+            targs = name.split("<")[-1].split(">")[0].replace(" ", "").split(",")
+            if k == "surfdisp_phase_kernel" and (targs[-1] == "true" or targs[-2] == "true"):
                 return None
-            if k == "surfdisp_group_kernel" and targs.endswith("true"):
+            if k == "surfdisp_group_kernel" and targs[-1] == "true":
                 return None
             return k
     return None
@@ -79,7 +80,7 @@ def main(tag):
             }
     out = {
         "round": tag,
-        "workload": "B=65536 L=10 P=20 Rayleigh c+U, team=4, two batches in flight",
+        "workload": "B=65536 L=10 P=20 Rayleigh c+U, default (point-by-point) scan, one batch in flight",
         "phase_kernel_hbm_bytes_per_launch": per_kernel.get("surfdisp_phase_kernel", {}).get("total"),
         "per_kernel": per_kernel,
         "valu": valu,
