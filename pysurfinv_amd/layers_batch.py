@@ -147,7 +147,10 @@ class Model1DBatch:
                         lay["Vs"] = [slot(v, f"{key}.Vs")]
                         lay["Vs_scalar"] = True
                 elif k == "deg":
-                    lay["deg"] = int(v)
+                    # only the mantle's Vs profile reads 'deg' (OceanMantle._calVs, layers.py:258-260); Crust._calVs
+                    # calls _bspl(z, nBasis) without it (layers.py:169-172)
+                    if kind == "mantle":
+                        lay["deg"] = int(v)
                 elif k in ("ThermAge", "Tp") and kind == "hybrid":
                     lay[k] = slot(v, f"{key}.{k}")
                 elif k == "Conversion" and kind == "hybrid":
@@ -156,6 +159,10 @@ class Model1DBatch:
                     lay[k] = v
                 elif k in ("Gauss",):
                     raise ValueError("Crust 'Gauss' option is out of scope")
+                elif _is_brownian_entry(v) or (isinstance(v, (list, tuple)) and any(_is_brownian_entry(e) for e in v)):
+                    # the reference's _brownians() would count it (models.py:240-253): silently dropping it would
+                    # shift every later mcTrack column against what PostPoint._loadMC expects
+                    raise ValueError(f"{key}.{k}: random-walk entry under a key Model1DBatch does not implement")
             if kind in ("water", "osedc"):
                 lay["Vs"] = []
             if kind == "hybrid":

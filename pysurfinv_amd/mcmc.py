@@ -84,20 +84,30 @@ class MetropolisBatch:
                                   nlay=nlay, independent=self.independent, fast_scan=self.fast_scan)
         return c.to(torch.float64), st
 
-    def misfit(self, params):
-        """(misfit, chiSqr, L) per chain - point.py:15-31."""
+    def misfit(self, params, rows=None, return_c=False):
+        """(misfit, chiSqr, L) per row of ``params`` - point.py:15-31.  With per-chain observations (``c_obs``
+        [C, P]) row i of ``params`` is compared with observation row i, or with row ``rows[i]`` when ``rows`` (an
+        index tensor) is given - the speculative sampler evaluates several proposals per chain, the grid driver
+        one average model per point."""
         torch = self.torch
         cP, st = self.forward_c(params)
         failed = (st != 0) | (cP < 0.01).any(dim=1)            # models.py:29-33
-        r = torch.where(self.mask, (self.c_obs - cP) / self.uncer, torch.zeros_like(cP))
+        c_obs, uncer, mask = self.c_obs, self.uncer, self.mask
+        if c_obs.ndim == 2:
+            if rows is not None:
+                c_obs, uncer, mask = c_obs[rows], uncer[rows], mask[rows]
+            elif c_obs.shape[0] != cP.shape[0]:
+                raise ValueError(f"{cP.shape[0]} models against {c_obs.shape[0]} rows of observations: pass rows=")
+        r = torch.where(mask, (c_obs - cP) / uncer, torch.zeros_like(cP))
         chi = (r * r).sum(dim=1)
-        N = self.mask.sum(dim=-1).to(torch.float64)
+        N = mask.sum(dim=-1).to(torch.float64)
         mis = torch.sqrt(chi / N)
         chi = torch.where(chi < 50, chi, torch.sqrt(chi * 50.0))
         L = torch.exp(-0.5 * chi)
         big = torch.full_like(chi, FAIL)
-        return (torch.where(failed, big, mis), torch.where(failed, big, chi),
-                torch.where(failed, torch.zeros_like(L), L))
+        out = (torch.where(failed, big, mis), torch.where(failed, big, chi),
+               torch.where(failed, torch.zeros_like(L), L))
+        return out + (cP,) if return_c else out
 
     # ------------------------------------------------------------------ proposals
     def _good(self, p):
@@ -226,7 +236,8 @@ class MetropolisBatch:
                 ks = torch.arange(lo, hi, device=self.device)
                 S[:, 2 * ks + 1] = q
                 S[:, 2 * ks + 2] = S[:, lo:hi]
-            misQ, chiQ, LQ = self.misfit(Q.reshape(-1, N))        # ONE forward solve of C*M stacks
+            # ONE forward solve of C*M stacks; proposal m of chain i is held against chain i's observations
+            misQ, chiQ, LQ = self.misfit(Q.reshape(-1, N), rows=ar.repeat_interleave(M) if self.c_obs.ndim == 2 else None)
             misQ, chiQ, LQ = misQ.reshape(C, M), chiQ.reshape(C, M), LQ.reshape(C, M)
             node = torch.zeros(C, dtype=torch.int64, device=self.device)
             for _ in range(min(d, chainL - i)):
@@ -242,15 +253,45 @@ class MetropolisBatch:
                 i += 1
         return track
 
-    def run_points(self, n_points, chains_per_point, chainL):
+    def run_points(self, n_points, chains_per_point, chainL, on_device=False):
         """MCinvMP for n_points at once: chain index = point * chains_per_point + k; chain k = 0 of
         every point starts at the initial model, the others at prior draws (point.py:95-99).
-        Returns numpy float64 [n_points, chains_per_point, chainL, 3+N]."""
+        Returns float64 [n_points, chains_per_point, chainL, 3+N] (numpy, or the device tensor)."""
         torch = self.torch
         C = n_points * chains_per_point
         first = (torch.arange(C, device=self.device) % chains_per_point) == 0
-        tr = self.run(C, chainL, init_first=False, _init_mask=first)
-        return tr.reshape(n_points, chains_per_point, chainL, -1).cpu().numpy()
+        tr = self.run(C, chainL, init_first=False, _init_mask=first).reshape(n_points, chains_per_point, chainL, -1)
+        return tr if on_device else tr.cpu().numpy()
+
+    def summarise_points(self, track, obs_rows):
+        """What the reference's ``PostPoint`` derives from one point's ``mcTrack`` (point.py:147-171), for all
+        points at once on the device.  ``track`` [n_points, R, 3+N] (R = chains * chainL rows per point, chains one
+        after the other as in the ``.npz``); ``obs_rows`` [n_points]: observation row of each point.
+
+        * rejected rows take the parameters of the last accepted row before them (``trueMarkovChain``, :154-159);
+        * ``minMod`` = row of the smallest misfit (:161-165); ``thres = max(2 min, min + 0.5)`` (:308-309);
+        * ``avgMod`` = mean of the parameters of all rows with misfit < thres (:166-169), forward-solved once more
+          for its misfit, likelihood (:171) and predicted curve (``pvelp``, model3D.py:32-35).
+        Returns float64 [n_points, 6 + 2N + P]: min_misfit, min_L, thres, n_accepted_final, avg_misfit, avg_L,
+        min_params[N], avg_params[N], pvelp[P]."""
+        torch = self.torch
+        npnt, R, W = track.shape
+        N = W - 3
+        acc = track[:, :, 2] > 0.5
+        idx = torch.arange(R, device=track.device)[None, :].expand(npnt, R)
+        last = torch.cummax(torch.where(acc, idx, torch.zeros_like(idx)), dim=1).values     # row 0 of a chain is accepted
+        paras = torch.gather(track[:, :, 3:], 1, last[:, :, None].expand(npnt, R, N))
+        mis = torch.nan_to_num(track[:, :, 0], nan=float("inf"))
+        imin = mis.argmin(dim=1)
+        ar = torch.arange(npnt, device=track.device)
+        min_mis, min_L, min_par = mis[ar, imin], track[ar, imin, 1], paras[ar, imin]
+        thres = torch.maximum(2.0 * min_mis, min_mis + 0.5)
+        final = mis < thres[:, None]
+        nfin = final.sum(dim=1)
+        avg_par = (paras * final[:, :, None]).sum(dim=1) / nfin.clamp(min=1)[:, None]
+        avg_mis, _, avg_L, cP = self.misfit(avg_par, rows=obs_rows, return_c=True)
+        return torch.cat([min_mis[:, None], min_L[:, None], thres[:, None], nfin.to(torch.float64)[:, None],
+                          avg_mis[:, None], avg_L[:, None], min_par, avg_par, cP], dim=1)
 
     def run_graphed(self, n_chains, chainL, init_first=True, rounds=24):
         """``run()`` with the whole Metropolis step - proposal, parameters -> stack, the forward

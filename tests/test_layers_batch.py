@@ -88,3 +88,20 @@ def test_native_params_to_model_kernel_matches_torch_path_and_reference():
     assert mo.native_descriptor() is None
     model, nlay = mo.to_model(torch.from_numpy(G["ocean/params"]).cuda())
     assert np.array_equal(nlay.cpu().numpy(), G["ocean/nlay"])
+
+
+def test_unknown_random_walk_keys_raise_and_crust_ignores_deg():
+    """A Brownian entry under a key the batch parser does not implement must not be dropped silently (the
+    reference's _brownians() would count it, models.py:240-253); 'deg' only acts on the mantle profile
+    (layers.py:169-172 vs 258-260)."""
+    import copy
+    from pysurfinv_amd.layers_batch import Model1DBatch
+    bad = copy.deepcopy(CONT)
+    bad["Crust"]["Moho"] = [0.0, "abs", 1.0, 0.1]
+    with pytest.raises(ValueError):
+        Model1DBatch(bad)
+    a = copy.deepcopy(CONT); a["Crust"]["deg"] = 2
+    ma, mb = Model1DBatch(a), Model1DBatch(CONT)
+    import torch
+    p = torch.as_tensor(np.asarray(mb.spec.v0)[None, :])
+    assert torch.equal(ma.to_model(p)[0], mb.to_model(p)[0])

@@ -212,3 +212,33 @@ def test_point_dropin_on_gpu(tmp_path):
     arr2 = p.MCinvMP(outdir=str(tmp_path / "mc"), pid="1_3", runN=64 * 12, chainL=12, seed=3, spec_depth=3, fast_scan=True)
     assert arr2.shape == arr.shape and np.isfinite(arr2).all()
     assert os.path.exists(tmp_path / "mc" / "1_3.npz")
+
+
+def test_speculative_sampler_with_per_chain_observations():
+    """spec_depth > 1 with c_obs [C, P] (the grid driver's case): proposal m of chain i is held against chain i's
+    observations.  Chains whose observations are shifted by +-5 % must end up with different misfits for the SAME
+    proposals, and the plain and the speculative sampler must both use every chain's own row."""
+    import torch
+    from pysurfinv_amd.layers_batch import Model1DBatch
+    from pysurfinv_amd.mcmc import MetropolisBatch
+    from oracle import cport
+    per = G["trace/periods"].astype(np.float32)
+
+    def fwd(model, nlay):
+        c, u, st = cport.forward_batch(model.cpu().numpy(), per, 2, nlay=None if nlay is None else nlay.cpu().numpy(), nthreads=2)
+        return torch.from_numpy(c.astype(np.float64)), torch.from_numpy(st)
+    mb = Model1DBatch(CONT)
+    C = 4
+    c_obs = np.tile(G["trace/c_obs"], (C, 1)) * np.array([1.0, 1.05, 0.95, 1.0])[:, None]
+    unc = np.tile(G["trace/uncer"], (C, 1))
+    mc = MetropolisBatch(mb.spec, mb.to_model, per, c_obs, unc, device="cpu", seed=4, forward=fwd)
+    tr = mc.run(C, 5, spec_depth=2)
+    assert tr.shape == (C, 5, 16) and np.isfinite(tr.numpy()).all()
+    # row 0 of every chain after the first is a prior draw; evaluate all four chains' observations on ONE model
+    p = torch.as_tensor(np.tile(mb.spec.v0, (C, 1)))
+    mis, chi, L = mc.misfit(p)
+    assert mis[0] == mis[3] and mis[1] != mis[0] and mis[2] != mis[0]
+    mis2, _, _ = mc.misfit(p[[0, 0]], rows=torch.tensor([1, 2]))
+    assert mis2[0] == mis[1] and mis2[1] == mis[2]
+    with pytest.raises(ValueError):
+        mc.misfit(p[:3])
