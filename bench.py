@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- layered-model dispersion forward solves/sec (20 periods) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload forward|grid|mcmc|c5]
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): batch of 65 536 MCMC-perturbed 10-layer stacks per GPU,
-Rayleigh phase + group velocity at 20 periods, synthetic inputs of SURVEY.md section 8(d).
-A "step" = one pass of the hot path (prep + root-search + group-velocity kernels) over one
-batch that is already resident in HBM.  The path shards over independent stacks: each rank
-owns its own batch (weak scaling), no data-path collective; the only communication is the
-barrier + MAX-reduce of the timing.
+Default workload `forward` (BASELINE.json configs[1], the configuration the metric is quoted on): a batch of
+65 536 MCMC-perturbed 10-layer stacks per GPU, Rayleigh phase + group velocity at 20 periods, synthetic inputs of
+SURVEY.md section 8(d).  A "step" = one pass of the hot path (prep + root search [+ exact fallback] + group velocity
++ finish kernels) over one batch that is already resident in HBM.  The path shards over independent stacks: each rank
+owns its own batch (weak scaling), no data-path collective; the only communication is the barrier + MAX-reduce of the
+timing.  `value` is measured with the library's DEFAULT scan (every 0.01 km/s grid point, as the reference).
 
-Prints ONE JSON line on rank 0 with metric/value plus:
-  roofline     - dominant kernel (root search), algorithmic bytes per launch / HIP-event duration
-  cpu_baseline - the reference Fortran (oracle/_ref, flang -O2) on one host core, bounded sample;
-                 the OpenMP C port on all cores is reported beside it.
+Prints ONE JSON line on rank 0 with metric / value plus
+  roofline     - dominant kernel (root search): bound "valu"; achieved = wave-level VALU instructions per launch
+                 (committed rocprofv3 --pmc pass of THIS library build, tagged) / live HIP-event duration, against
+                 1024 SIMDs x one instruction per 2 cycles; the HBM figure north_star asks for is beside it
+  cpu_baseline - the reference Fortran (oracle/_ref, flang -O2) on one host core, bounded sample; the OpenMP C port
+                 on all cores beside it
+  parity       - max relative error of c and U of the first 1024 stacks of the bench batch against the CPU oracle
+                 (computed in the cpu_baseline leg, outside every timed region)
+  workloads    - unless --workload names a single one: short legs of the other BASELINE configs on the same rank(s):
+                 grid (configs[3] share: 512 points x 50 chains per GPU, lock-step Metropolis), mcmc (configs[2]),
+                 c5 (configs[4]: joint R+L 64-layer thermal stacks + analytic sensitivity kernels)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -33,10 +41,39 @@ NPER = 20
 KIND = 2 | int(os.environ.get("BENCH_KIND_FLAGS", "0"), 0)   # Rayleigh (c + U); development: extra kind flags
 ALG_BYTES_PER_SOLVE = 20 * NLAY + 8 * NPER    # 5 fp32 arrays in, (c, U) out = 360 B
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+SIMDS, CLOCK_HZ = 1024, 2.4e9 # 256 CUs x 4 SIMDs, max clock
+VALU_PEAK = SIMDS * CLOCK_HZ / 2.0            # wave-level VALU instructions / s (one per 2 cycles per SIMD)
+
+# the continental model of the Metropolis legs: sediment + 4-coefficient crust + 5-coefficient mantle + reference
+# mantle = 96 layers, 13 random-walk parameters (the setting the driver golden vectors were captured with)
+MCMC_SETTING = {
+    'Sediment': {'H': [2., 'abs_pos', 1.5, 0.1], 'Vs': [[1.5, 'abs', 0.5, 0.05], [2.2, 'abs', 0.5, 0.05]]},
+    'Crust': {'H': [35., 'abs', 10., 1.0],
+              'Vs': [[3.4, 'abs', 0.3, 0.02], [3.6, 'abs', 0.3, 0.02], [3.8, 'abs', 0.3, 0.02], [3.9, 'abs', 0.3, 0.02]]},
+    'Mantle': {'H': 160., 'Vs': [[4.4, 'abs', 0.4, 0.02], [4.35, 'abs', 0.4, 0.02], [4.4, 'abs', 0.4, 0.02],
+                                 [4.5, 'abs', 0.4, 0.02], [4.6, 'abs', 0.4, 0.02]]},
+    'Info': {'modelType': 'MCInv', 'refLayer': True},
+}
+MCMC_PERIODS = [8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 50, 60, 70, 80]
+C5_SETTING = {
+    'OceanWater': {'H': 2.6},
+    'OceanSedimentCascadia': {'H': [0.3, 'abs', 0.2, 0.03]},
+    'OceanCrust': {'H': 4.4, 'Vs': [3.25, 3.94]},
+    'OceanMantleHybrid': {'BottomDepth': 200, 'Conversion': 'Ritzwoller', 'ThermAge': [4, 'rel_pos', 200, 0.4],
+                          'Vs': [[0, 'abs', 0.2, 0.01], [0, 'abs', 0.2, 0.01], [0, 'abs', 0.2, 0.01], [0, 'abs', 0.1, 0.01]]},
+    'Info': {'modelType': 'MCInv', 'period': 10, 'refLayer': False},
+}
 
 
-def cpu_baseline(per):
-    """Bounded CPU sample on the host cores (rank 0, N=1 only).  Checker code, timed - never the product."""
+def lib_hash():
+    from pysurfinv_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def cpu_baseline(per, c_gpu, u_gpu):
+    """Bounded CPU sample on the host cores (rank 0, N=1 only).  Checker code, timed - never the product.  Also the
+    parity figure of the bench batch: its first 1024 stacks through the CPU oracle."""
     from pysurfinv_amd import synth
     from oracle import cport, refso
     try:
@@ -49,19 +86,19 @@ def cpu_baseline(per):
     if refso.available():
         n = 6144                                     # ~9 s at ~700 solves/s/core
         t0 = time.perf_counter()
-        refso.forward_batch(sample[:n, 0], sample[:n, 1], sample[:n, 2], sample[:n, 3], sample[:n, 4], per, KIND)
+        refso.forward_batch(sample[:n, 0], sample[:n, 1], sample[:n, 2], sample[:n, 3], sample[:n, 4], per, KIND & 3)
         dt = time.perf_counter() - t0
         out = {"value": n / dt, "unit": "solves/s", "cores": 1, "kind": "reference",
                "sample": f"first {n} of the bench batch (B=65536 L=10 P=20 Rayleigh c+U), "
                          "unmodified fast_surf Fortran built by oracle/build_ref.sh (flang -O2), "
                          "non-reentrant so one core"}
     # the reentrant C port, all host cores
-    cport.forward_batch(sample[:256], per, KIND, nthreads=ncores)
+    cport.forward_batch(sample[:256], per, KIND & 3, nthreads=ncores)
     t0 = time.perf_counter()
-    cport.forward_batch(sample, per, KIND, nthreads=ncores)
+    co, uo, so = cport.forward_batch(sample, per, KIND & 3, nthreads=ncores)
     dtp = time.perf_counter() - t0
     t0 = time.perf_counter()
-    cport.forward_batch(sample[:2048], per, KIND, nthreads=1)
+    cport.forward_batch(sample[:2048], per, KIND & 3, nthreads=1)
     dt1 = time.perf_counter() - t0
     port = {"value": sample.shape[0] / dtp, "unit": "solves/s", "cores": ncores, "kind": "port",
             "sample": "8192 stacks of the bench batch, oracle/surfdisp_oracle.c with OpenMP",
@@ -70,63 +107,92 @@ def cpu_baseline(per):
         out = dict(port)
     else:
         out["port_all_cores"] = port
-    return out
+    n = 1024
+    rel = lambda x, r: float(np.max(np.abs(x[r != 0].astype(np.float64) / r[r != 0] - 1.0)))
+    parity = {"max_rel_err_c": rel(c_gpu[:n], co[:n]), "max_rel_err_u": rel(u_gpu[:n], uo[:n]),
+              "zero_pattern_equal": bool(np.array_equal(c_gpu[:n] > 0, co[:n] > 0)), "stacks": n, "bar": 1e-4,
+              "against": "oracle/surfdisp_oracle.c (bit-exact restatement of the reference Fortran, tests/test_oracle.py), "
+                         "first 1024 stacks of rank 0's bench batch, outside every timed region"}
+    return out, parity
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    import torch
-    from pysurfinv_amd import _lib, forward, synth
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
+# ------------------------------------------------------------------------------------------------ helpers
+class Runtime:
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if args.gpus != self.world and self.world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # nccl == RCCL on ROCm.  BENCH_REHEARSAL=1 (development only): all ranks share cuda:0 and
-        # rendezvous over gloo, to exercise this code path on a one-GPU box.
-        rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
-        if rehearsal:
-            local_rank = 0
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device(f"cuda:{local_rank}"))
-    dev = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(dev)
-    if _lib.lib().surfdisp_device_count() < 1:
-        raise SystemExit("no HIP device: the product path has no CPU fallback")
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            # nccl == RCCL on ROCm.  BENCH_REHEARSAL=1 (development only): all ranks share cuda:0 and
+            # rendezvous over gloo, to exercise this code path on a one-GPU box.
+            if os.environ.get("BENCH_REHEARSAL") == "1":
+                local_rank = 0
+                dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group(backend="nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device(f"cuda:{local_rank}"))
+            self.dist = dist
+        self.dev = torch.device(f"cuda:{local_rank}")
+        torch.cuda.set_device(self.dev)
+        self.rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
 
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, *vals):
+        """MAX over ranks of each value (every timing of the line goes through here)."""
+        if self.dist is None:
+            return [float(v) for v in vals]
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=None if self.rehearsal else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
+    def sum_over_ranks(self, *vals):
+        if self.dist is None:
+            return [int(v) for v in vals]
+        t = self.torch.tensor(list(vals), dtype=self.torch.int64, device=None if self.rehearsal else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [int(x) for x in t.tolist()]
+
+    def timed(self, fn, steps, warmup):
+        """`warmup` untimed calls, then EXACTLY `steps` calls bracketed by barrier + synchronize on both sides;
+        returns the MAX over ranks of the elapsed seconds."""
+        for _ in range(warmup):
+            fn()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)[0]
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def workload_forward(rt, args):
+    torch = rt.torch
+    from pysurfinv_amd import _lib, forward, synth
+    dev, world, rank = rt.dev, rt.world, rt.rank
     per_np = synth.default_periods(NPER)
     model = torch.from_numpy(synth.synth_models(B_PER_GPU, NLAY, seed=rank)).to(dev)
     per = torch.from_numpy(per_np).to(dev)
-    # Two batches in flight on two HIP streams: the root-search kernel's wavefronts finish at
-    # different times, and a second independent batch fills the idle SIMD slots (measured +15 %).
-    # Same work per step; the one-batch-in-flight rate is reported beside it.  With a second batch in
-    # flight the launches carry SURFDISP_PIPELINED (lanes per stack chosen for both batches: 2 instead
-    # of 4 here, +6 % measured); results are identical for every team size (tests/test_gpu_parity.py).
+    # Two batches in flight on two HIP streams: each batch is ONE wave of work for the chip (65 536 teams, fewer
+    # than the lanes it holds), its wavefronts finish at different times, and a second independent batch fills the
+    # SIMD slots the first one vacates.  Same work per step; the one-batch-in-flight rate is reported beside it.
+    # With a second batch in flight the launches carry SURFDISP_PIPELINED (lanes per stack chosen for both batches);
+    # results are identical for every team size (tests/test_gpu_parity.py).
     NFLIGHT = int(os.environ.get("BENCH_IN_FLIGHT", "2"))
     plans = [forward.BatchPlan(B_PER_GPU, NLAY, NPER, device=dev) for _ in range(NFLIGHT)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NFLIGHT)]
-    plan = plans[0]
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
     ring = forward.EventRing(args.steps)       # HIP events recorded on the launch stream, read after the sync
 
     def steps(n, nflight, record=False, fast_scan=False):
@@ -136,103 +202,252 @@ def main():
                                        pipelined=nflight > 1, fast_scan=fast_scan)
 
     steps(max(args.warmup, NFLIGHT), NFLIGHT)
-    barrier()
+    rt.barrier()
     t0 = time.perf_counter()
     steps(args.steps, 1, record=True)                      # one batch in flight (reported beside value);
-    barrier()                                              # its kernels are bracketed by HIP events
+    rt.barrier()                                           # its kernels are bracketed by HIP events
     elapsed_one = time.perf_counter() - t0
     kms = ring.kernel_ms().mean(axis=0)                    # live: average over the K timed launches
     steps(args.warmup, NFLIGHT)
-    barrier()
+    rt.barrier()
     t0 = time.perf_counter()
-    steps(args.steps, NFLIGHT)
-    barrier()
+    steps(args.steps, NFLIGHT)                             # THE timed region of `value`
+    rt.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # beside the headline: the same workload with SURFDISP_EXACTSCAN (every scan grid point evaluated, as the
-    # reference does; the default steps over certified intervals - bit-identical outputs, include/surfdisp.h)
+    # beside the headline: the same workload with the opt-in heuristic scan (SURFDISP_FASTSCAN, include/surfdisp.h)
     steps(args.warmup, NFLIGHT, fast_scan=True)
-    barrier()
+    rt.barrier()
     t0 = time.perf_counter()
     steps(args.steps, NFLIGHT, fast_scan=True)
-    barrier()
+    rt.barrier()
     elapsed_fast = time.perf_counter() - t0
-    steps(1, 1)                                            # leave the default mode's results in the plans
-    barrier()
+    elapsed, elapsed_one, elapsed_fast = rt.max_over_ranks(elapsed, elapsed_one, elapsed_fast)
+    steps(1, 1)                                            # leave the default mode's results in plan 0
+    rt.barrier()
+    # every stack of every rank must have been solved (work was not skipped); none took the exact fallback
+    n_ok, n_fb = rt.sum_over_ranks(min(int((p.status == 0).sum().item()) for p in plans), plans[0].fallback_count())
 
-    # every stack of every rank must have been solved (work was not skipped)
-    n_ok = min(int((p.status == 0).sum().item()) for p in plans)
-    ok = torch.tensor([n_ok], dtype=torch.int64, device=dev)
-    if dist is not None:
-        dist.all_reduce(ok, op=dist.ReduceOp.SUM)
+    if rank != 0:
+        return None
+    phase_s = kms[1] * 1e-3
+    hbm_achieved = ALG_BYTES_PER_SOLVE * B_PER_GPU / phase_s / 1e9
+    roof = {"bound": "valu", "kernel": "surfdisp_phase_kernel", "unit": "wave-level VALU instructions/s",
+            "peak": VALU_PEAK, "achieved": None, "frac": None, "traffic": None,
+            "hbm": {"achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
+                    "note": "algorithmic bytes = 360 B/solve x 65536 solves per launch / live kernel duration: the "
+                            "figure north_star asks for; the path is not HBM-bound (SURVEY.md 8(d))"}}
+    tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    here = lib_hash()
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            v = tj.get("valu", {}).get("surfdisp_phase_kernel", {})
+            same = tj.get("lib_sha256_16") == here
+            roof.update({"achieved": v["valu_wave_instructions"] / phase_s,
+                         "frac": v["valu_wave_instructions"] / phase_s / VALU_PEAK,
+                         "traffic": tj.get("phase_kernel_hbm_bytes_per_launch"),
+                         "valu_pmc": v, "pmc_profile": tj.get("round"), "pmc_lib_sha256_16": tj.get("lib_sha256_16"),
+                         "this_lib_sha256_16": here, "pmc_matches_this_build": bool(same),
+                         "note": "achieved = wave-level VALU instructions per launch (SQ_INSTS_VALU of the committed "
+                                 "rocprofv3 --pmc pass named in pmc_profile) / the LIVE duration of the kernel (HIP "
+                                 "events on its stream); peak = 1024 SIMDs x 2.4 GHz / 2 cycles per instruction (quarter-"
+                                 "rate transcendentals are 8 % of the stream, so the pipe is busier than frac says); "
+                                 "traffic = HBM bytes per launch from the same passes (FETCH_SIZE x 2 + WRITE_SIZE)"
+                                 + ("" if same else "; WARNING: the profile was taken with another build of the library")})
+        except Exception as e:                                   # a broken profile file must not kill the line
+            roof["note"] = f"profiles/traffic_latest.json unreadable: {e}"
+    line = {
+        "metric": "layered-model dispersion forward solves/sec (20 periods)",
+        "value": world * B_PER_GPU * args.steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (root search, Love group velocity) + f64 (Rayleigh eigenfunction state)",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: 65536 MCMC-perturbed 10-layer stacks per GPU, "
+                               "Rayleigh phase+group velocity at 20 periods",
+                   "stacks_per_gpu": B_PER_GPU, "layers": NLAY, "periods": NPER,
+                   "wave": "Rayleigh c+U", "scan": "default: every 0.01 km/s grid point, as the reference",
+                   "batches_in_flight": NFLIGHT,
+                   "team_lanes": int(_lib.lib().surfdisp_get_team(B_PER_GPU * (2 if NFLIGHT > 1 else 1), NLAY)),
+                   "team_lanes_one_batch_in_flight": int(_lib.lib().surfdisp_get_team(B_PER_GPU, NLAY)),
+                   "sharding": f"independent stacks, {world} rank(s), no data-path collective"},
+        "solved_fraction": n_ok / (world * B_PER_GPU),
+        "stacks_through_exact_fallback": n_fb,
+        "value_one_batch_in_flight": world * B_PER_GPU * args.steps / elapsed_one,
+        "value_fast_scan": world * B_PER_GPU * args.steps / elapsed_fast,
+        "kernel_ms": {"prep": kms[0], "phase": kms[1], "group_and_finish": kms[2],
+                      "how": "HIP events recorded on the launch stream around each kernel of the K timed "
+                             "one-batch-in-flight steps, read after the closing synchronisation; phase = root search + "
+                             "the (idle) exact fallback launch behind it"},
+        "roofline": roof,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"], line["parity"] = cpu_baseline(per_np, plans[0].c.cpu().numpy(), plans[0].u.cpu().numpy())
+    return line
 
 
-    if rank == 0:
-        total_solves = world * B_PER_GPU * args.steps
-        value = total_solves / elapsed
-        phase_s = kms[1] * 1e-3
-        achieved = ALG_BYTES_PER_SOLVE * B_PER_GPU / phase_s / 1e9
-        traffic, valu = None, None
-        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                traffic = tj.get("phase_kernel_hbm_bytes_per_launch")
-                valu = tj.get("valu", {}).get("surfdisp_phase_kernel")
-            except Exception:
-                traffic = None
-        recursion = None
-        rfile = os.path.join(ROOT, "profiles", "recursion_ceiling.json")
-        if os.path.exists(rfile):
-            try:
-                rj = json.load(open(rfile))
-                ev = rj["evaluations_per_stack_default_scan"] * B_PER_GPU / phase_s
-                recursion = {"achieved": ev, "peak": rj["ceiling_evaluations_per_s_no_divergence"],
-                             "unit": "secular-function evaluations/s", "frac": ev / rj["ceiling_evaluations_per_s_no_divergence"],
-                             "note": "secular-function evaluations of the default scan per stack (counted with an instrumented "
-                                     "build, committed in profiles/recursion_ceiling.json) / live root-search kernel time, "
-                                     "against the bare recursion's measured rate (scripts/microbench/issue_rate.hip)"}
-            except Exception:
-                recursion = None
-        line = {
-            "metric": "layered-model dispersion forward solves/sec (20 periods)",
-            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (root search, Love group velocity) + f64 (Rayleigh eigenfunction state)",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 65536 MCMC-perturbed 10-layer stacks per GPU, "
-                                   "Rayleigh phase+group velocity at 20 periods",
-                       "stacks_per_gpu": B_PER_GPU, "layers": NLAY, "periods": NPER,
-                       "wave": "Rayleigh c+U", "batches_in_flight": NFLIGHT,
-                       "team_lanes": int(_lib.lib().surfdisp_get_team(B_PER_GPU * (2 if NFLIGHT > 1 else 1), NLAY)),
-                       "team_lanes_one_batch_in_flight": int(_lib.lib().surfdisp_get_team(B_PER_GPU, NLAY)),
-                       "sharding": f"independent stacks, {world} rank(s), no data-path collective"},
-            "solved_fraction": float(ok.item()) / (world * B_PER_GPU),
-            "value_one_batch_in_flight": world * B_PER_GPU * args.steps / elapsed_one,
-            "value_fast_scan": B_PER_GPU * args.steps / elapsed_fast,         # this rank, opt-in SURFDISP_FASTSCAN
-            "kernel_ms": {"prep": kms[0], "phase": kms[1], "group_and_finish": kms[2],
-                          "how": "HIP events recorded on the launch stream around each kernel of the K timed "
-                                 "one-batch-in-flight steps, read after the closing synchronisation"},
-            "roofline": {"bound": "hbm", "kernel": "surfdisp_phase_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "valu_pmc": valu,
-                         "recursion_ceiling": recursion,
-                         "note": "algorithmic bytes = 360 B/solve x 65536 solves per launch; the path is "
-                                 "VALU/transcendental-bound, not HBM-bound (SURVEY.md 8(d)); traffic and "
-                                 "valu_pmc come from the committed rocprofv3 --pmc passes (profiles/)"},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(per_np)
+def _mcmc_setup(rt, n_points, chains):
+    """Continental model + synthetic per-point observations: the model's own curve at a random 'true' parameter vector
+    per point (prior draw shrunk towards the start model), 1 % uncertainty."""
+    torch = rt.torch
+    from pysurfinv_amd.layers_batch import Model1DBatch
+    from pysurfinv_amd.brownian import TorchProposer
+    mb = Model1DBatch(MCMC_SETTING, device=rt.dev)
+    pr = TorchProposer(mb.spec, rt.dev, seed=100 + rt.rank)
+    v0 = torch.as_tensor(mb.spec.v0, dtype=torch.float64, device=rt.dev)[None, :]
+    truth = v0 + 0.3 * (pr.reset(n_points) - v0)
+    c_true, st = mb.forward(truth, periods=MCMC_PERIODS)
+    c0, _ = mb.forward(v0, periods=MCMC_PERIODS)
+    c_true = torch.where((st != 0)[:, None] | (c_true < 0.01), c0.expand_as(c_true), c_true)   # unsolved draw: start model's curve
+    c_obs = c_true.double().cpu().numpy()
+    return mb, c_obs, 0.01 * c_obs
+
+
+def workload_grid(rt, args, steps=None, warmup=None):
+    """BASELINE configs[3], one lock step = one Metropolis step of every chain of every point a rank owns (512 points
+    x 50 chains = 25 600 chains per GPU; 4 096 points on 8 GPUs): parameters -> 96-layer stacks (HIP), one batched
+    phase-only forward solve, misfit + accept (torch).  Weak scaling over points; no data-path collective."""
+    torch = rt.torch
+    from pysurfinv_amd.mcmc import MetropolisBatch
+    pts, chains = int(os.environ.get("BENCH_GRID_POINTS", "512")), int(os.environ.get("BENCH_GRID_CHAINS", "50"))
+    K = steps if steps is not None else args.steps
+    W = warmup if warmup is not None else args.warmup
+    mb, c_obs, unc = _mcmc_setup(rt, pts, chains)
+    rep = lambda a: np.repeat(a, chains, axis=0)
+    mc = MetropolisBatch(mb.spec, mb.to_model, MCMC_PERIODS, rep(c_obs), rep(unc), device=rt.dev, seed=7 + rt.rank)
+    C = pts * chains
+    state = {}
+
+    def setup():
+        state["p"] = mc.reset(C)
+        state["chi"] = mc.misfit(state["p"])[1]
+
+    def step():
+        p1 = mc.perturb(state["p"])
+        mis1, chi1, L1 = mc.misfit(p1)
+        better = chi1 < state["chi"]
+        u = mc.proposer.uniform(C)
+        acc = better | (~better & (u > 1.0 - torch.exp(-(chi1 - state["chi"]) / 2.0)))
+        state["p"] = torch.where(acc[:, None], p1, state["p"])
+        state["chi"] = torch.where(acc, chi1, state["chi"])
+        state["acc"] = acc
+
+    setup()
+    n0 = mc.n_forward
+    elapsed = rt.timed(step, K, W)
+    L = int(mb.to_model(state["p"][:4])[0].shape[2])
+    acc_rate, = rt.max_over_ranks(float(state["acc"].double().mean()))
+    return {"metric": "Metropolis steps/s, model3D grid share (BASELINE configs[3])", "unit": "steps/s",
+            "value": rt.world * C * K / elapsed, "forward_solves_per_s": rt.world * C * K / elapsed,
+            "ms_per_step": elapsed / K * 1e3, "steps": K, "warmup": W, "n_gpus": rt.world, "scaling": "weak",
+            "config": {"workload": "BASELINE configs[3] share per GPU: 512 points x 50 chains, 96-layer continental model, "
+                                   "19 periods, Rayleigh phase-only misfit, default scan",
+                       "points_per_gpu": pts, "chains_per_point": chains, "chains_per_gpu": C, "layers": L,
+                       "periods": len(MCMC_PERIODS)},
+            "accept_rate_last_step": acc_rate, "forward_solves_timed_this_rank": int(mc.n_forward - n0)}
+
+
+def workload_mcmc(rt, args, steps=None, warmup=None):
+    """BASELINE configs[2]: one surface point, 100 000 Metropolis steps as 100 chains x 1000 (the reference's
+    MCinvMP layout, point.py:90-125), here the rate of the lock step (100 chains), plain and replayed from a HIP graph."""
+    from pysurfinv_amd.mcmc import MetropolisBatch
+    K = steps if steps is not None else max(args.steps, 50)
+    mb, c_obs, unc = _mcmc_setup(rt, 1, 100)
+    out = {"metric": "Metropolis steps/s, single point (BASELINE configs[2])", "unit": "steps/s", "n_gpus": rt.world,
+           "config": {"workload": "BASELINE configs[2]: one point, 100 chains in lock step (100 000 steps = 1000 lock steps), "
+                                  "96-layer continental model, 19 periods, Rayleigh phase-only misfit", "chains": 100}}
+    mc = MetropolisBatch(mb.spec, mb.to_model, MCMC_PERIODS, c_obs[0], unc[0], device=rt.dev, seed=3 + rt.rank)
+    mc.run(100, 4); rt.barrier()
+    t0 = time.perf_counter(); mc.run(100, K + 1); rt.barrier()
+    dt, = rt.max_over_ranks(time.perf_counter() - t0)
+    out.update({"value": rt.world * 100 * K / dt, "ms_per_lock_step": dt / K * 1e3, "steps": K})
+    try:
+        mc.run_graphed(100, 8); rt.barrier()
+        t0 = time.perf_counter(); mc.run_graphed(100, 4 * K + 2); rt.barrier()
+        dtg, = rt.max_over_ranks(time.perf_counter() - t0)
+        out.update({"value_hip_graph": rt.world * 100 * 4 * K / dtg, "ms_per_lock_step_hip_graph": dtg / (4 * K) * 1e3,
+                    "seconds_for_100000_steps_hip_graph": 1000 * dtg / (4 * K)})
+    except Exception as e:
+        out["hip_graph_error"] = repr(e)[:200]
+    return out
+
+
+def workload_c5(rt, args, steps=None, warmup=None):
+    """BASELINE configs[4] per GPU: 16 384 ThermSeis-derived 64-layer stacks (water + Cascadia sediment + crust + thermal
+    mantle: parameters -> stacks on the device), joint Rayleigh + Love phase + group velocity at 20 periods, and the
+    analytic sensitivity kernels dc/d(Vs, Vp, rho) of every layer."""
+    torch = rt.torch
+    from pysurfinv_amd import forward, senskernel, synth
+    from pysurfinv_amd.brownian import TorchProposer
+    from pysurfinv_amd.layers_batch import Model1DBatch
+    B = int(os.environ.get("BENCH_C5_STACKS", "16384"))
+    K = steps if steps is not None else max(3, args.steps // 4)
+    W = warmup if warmup is not None else 1
+    per = torch.from_numpy(synth.default_periods(20)).to(rt.dev)
+    mb = Model1DBatch(C5_SETTING, device=rt.dev)
+    params = TorchProposer(mb.spec, rt.dev, seed=1 + rt.rank).reset(B)
+    st = {}
+
+    def gen():
+        st["model"], st["nlay"] = mb.to_model(params)
+    t_gen = rt.timed(gen, K, W)
+    L = int(st["model"].shape[2])
+    plan = forward.JointPlan(B, L, 20, device=rt.dev)
+    t_joint = rt.timed(lambda: plan.run(st["model"], per, nlay=st["nlay"]), K, W)
+    t_kr = rt.timed(lambda: senskernel.analytic_kernels(st["model"], per, wtype="R", nlay=st["nlay"]), K, W)
+    t_kl = rt.timed(lambda: senskernel.analytic_kernels(st["model"], per, wtype="L", nlay=st["nlay"]), K, W)
+    out = plan.run(st["model"], per, nlay=st["nlay"]); rt.barrier()
+    okR, okL = float((out["statusR"] == 0).float().mean()), float((out["statusL"] == 0).float().mean())
+    w = rt.world
+    return {"metric": "joint R+L c+U forward solves/s + sensitivity kernels, 64-layer thermal stacks (BASELINE configs[4])",
+            "unit": "solves/s", "value": w * 2 * B * K / t_joint, "n_gpus": w, "steps": K, "scaling": "weak",
+            "config": {"workload": "BASELINE configs[4] per GPU: 16384 ThermSeis-derived stacks, joint Rayleigh+Love c+U at 20 "
+                                   "periods, analytic sensitivity kernels", "stacks_per_gpu": B, "layers": L, "periods": 20},
+            "ms_thermal_parameters_to_stacks": t_gen / K * 1e3, "ms_joint_R_L_c_U": t_joint / K * 1e3,
+            "ms_forward_plus_kernels_R": t_kr / K * 1e3, "ms_forward_plus_kernels_L": t_kl / K * 1e3,
+            "kernel_sets_per_s_R": w * B * K / t_kr, "kernel_sets_per_s_L": w * B * K / t_kl,
+            "solved_fraction_R": okR, "solved_fraction_L": okL}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["all", "forward", "grid", "mcmc", "c5"], default="all",
+                    help="all (default): the forward headline line + short legs of the other BASELINE configs inside it; "
+                         "a single name: only that workload, as the line itself")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from pysurfinv_amd import _lib
+    rt = Runtime(args)
+    if _lib.lib().surfdisp_device_count() < 1:
+        raise SystemExit("no HIP device: the product path has no CPU fallback")
+
+    single = {"grid": workload_grid, "mcmc": workload_mcmc, "c5": workload_c5}
+    if args.workload in single:
+        line = single[args.workload](rt, args)
+        line.update({"higher_is_better": True, "data": "synthetic", "vs_baseline": None})
+    else:
+        line = workload_forward(rt, args)
+        if args.workload == "all":
+            extra = {}
+            for name, fn, kw in (("grid", workload_grid, dict(steps=10, warmup=2)),
+                                 ("mcmc", workload_mcmc, dict(steps=60)),
+                                 ("c5", workload_c5, dict(steps=3, warmup=1))):
+                try:
+                    extra[name] = fn(rt, args, **kw)
+                except Exception as e:                          # a side leg must never cost the headline line
+                    extra[name] = {"error": repr(e)[:300]}
+                    rt.barrier()
+            if line is not None:
+                line["workloads"] = extra
+    if rt.rank == 0 and line is not None:
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rt.dist is not None:
+        rt.dist.barrier()
+        rt.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -526,7 +526,7 @@ __device__ __forceinline__ int drop_layers(const float *wq, const int Lcap, cons
 // developer build (make stats): pass counters of the root search, read through surfdisp_stats() in this file
 __device__ unsigned long long g_stats[24];
 #endif
-enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3 };
+enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3, ST_NEVILL = 4 };
 
 
 // INDEP = false: "faithful" - a team owns a stack and walks its periods in order (reference
@@ -539,14 +539,16 @@ enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3 };
 // FAST = true: opt-in heuristic coarse-to-fine scan (SURFDISP_FASTSCAN; instantiated for teams of 2, 4 and 8 lanes
 // only); FAST = false: every grid point, as the reference - the default, and all larger teams.
 // EXACT = false: the production root search - factorised Rayleigh recursion, team subdivision + interpolation
-//   instead of NEVILL.  A team that meets what those two cannot reproduce faithfully - a secular function that
-//   leaves the fp32 range (the reference's overflow points depend on how it forms its matrix entries) or a
-//   bracket with more than one visible sign change (which of several roots NEVILL lands on depends on its
-//   evaluation sequence) - appends its stack to A.fb_list and stops.
-// EXACT = true : the fallback that re-solves the listed stacks from their first period: the reference's own
-//   matrix-entry arithmetic (delta_rayleigh<false>) and a statement-by-statement NEVILL (surfa.f:2-83), one
-//   evaluation per pass, every lane of the team at the same trial velocity.  Rare by construction, so its speed
-//   does not matter; launched after the production kernel with a grid for the worst case, idle blocks exit.
+//   instead of NEVILL.  Two things those cannot reproduce faithfully:
+//   * a bracket with more than one visible sign change - which of several roots NEVILL lands on depends on its
+//     evaluation sequence: the team then runs a statement-by-statement NEVILL (surfa.f:2-83, state ST_NEVILL: one
+//     evaluation per pass, every lane of the team at the same trial velocity) for that period;
+//   * a secular function that leaves the fp32 range - the reference's overflow points depend on how it forms
+//     its matrix entries: the team appends its stack to A.fb_list and stops.
+// EXACT = true : the fallback that re-solves the listed stacks from their first period with the reference's own
+//   matrix-entry arithmetic (delta_rayleigh<false>) and NEVILL for every root.  Only stacks that overflow fp32 get
+//   here (physical models never do), so its speed does not matter; launched after the production kernel with a
+//   grid for the worst case, idle blocks exit at once.
 template <int KIND, int G, bool INDEP, bool FAST = false, bool EXACT = false>
 __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArgs A)
 {
@@ -579,8 +581,8 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
     const bool want_ratio = (KIND == 2) && (A.ratio != nullptr);
     const bool OVERLAP = !EXACT && want_ratio && (G >= 4) && !INDEP && (A.overlap != 0);
     float *wq2 = w_lds + (size_t)NFW * Lcap * S + slot;
-    // EXACT: NEVILL's interpolation table x(1..11), y(1..11) (surfa.f:8) of this team, behind the working stacks
-    float *nvx = w_lds + (size_t)NFW * Lcap * S + (size_t)slot * 24, *nvy = nvx + 12;
+    // NEVILL's interpolation table x(1..11), y(1..11) (surfa.f:8) of this team, behind the working stacks
+    float *nvx = w_lds + (size_t)((!EXACT && G >= 4 && A.overlap != 0) ? 2 : 1) * NFW * Lcap * S + (size_t)slot * 24, *nvy = nvx + 12;
     const float *__restrict__ mdl = A.mdl;
     const size_t fs = (size_t)Lcap * B;
 
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
     bool ell_pend = false;
     int ell_k = 0, ell_mm = 2;
     float ell_c = 1.0f, ell_T = 1.0f;
-    // EXACT: NEVILL's state between two evaluations (c1, del1 = p0c, p0d; c2, del2 = cb, db; c3 = croot)
+    // NEVILL's state between two evaluations (c1, del1 = p0c, p0d; c2, del2 = cb, db; c3 = croot)
     int nv_nev = 1, nv_m = 1, nv_ic = 0;
     bool defer = false;                // !EXACT: this stack goes to the exact fallback kernel
 
@@ -720,7 +722,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
                 for (int i = 0; i < G; ++i) if (i < nadd) cj = cj + DC;
             }
             mmj = drop_layers(wq, Lcap, S, n, cj, T);          // idrop=0 before every scan trial
-        } else if (EXACT && st == ST_REFINE) {
+        } else if (st == ST_NEVILL) {
             cj = croot; mmj = mm_frozen;                       // NEVILL's c3, idrop = 1
         } else if (st == ST_REFINE) {
             const float w = cb - p0c;
@@ -882,12 +884,15 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         // What NEVILL cannot do is separate two fp32 numbers above 16 km/s (spacing 1.9e-6 > its 1e-6 tolerance,
         // surfa.f:10,44): its 50-cycle limit trips (surfa.f:17-27), calcul.f:172-189 jumps to 9999 and the whole
         // call returns nothing, also the periods already solved - SURFDISP_NUMERIC (see `fatal` in REFINE below).
-        bool fatal = false;
+        bool fatal = false, multi = false;
         if (!EXACT) {
-            // what this kernel does not reproduce faithfully goes to the exact fallback (see the template flags)
+            // what this kernel does not reproduce faithfully (see the template flags)
             const bool nonfin = ((__ballot(eval && !fin(val)) & tmask) != 0ull);
-            const int ncross = __popcll(__ballot(searching && cross) & tmask) + ((negnan(l_d) != negnan(db)) ? 1 : 0);
-            if (st != ST_DONE && (nonfin || (st == ST_REFINE && ncross >= 2))) defer = true;
+            if (st != ST_DONE && nonfin) defer = true;         // -> exact fallback kernel
+            if (st == ST_REFINE && passes == 0) {              // first refine pass: sign changes across the bracket
+                const int ncross = __popcll(__ballot(searching && cross) & tmask) + ((negnan(l_d) != negnan(db)) ? 1 : 0);
+                multi = ncross >= 2;                           // -> NEVILL for this period
+            }
         }
         if (OVERLAP && ell_pend && st == ST_SCAN) {
             if (j == 0) A.ratio[(size_t)ell_k * B + b] = 0.5f * v1 / v0;   // surfa.f:363
@@ -919,6 +924,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
                 if (EXACT) {                                   // NEVILL's prologue, surfa.f:12-16
                     nv_ic = 0; nv_nev = 1; nv_m = 1;
                     croot = (p0c + cb) / 2.0f;                 // c3, evaluated by the next pass
+                    st = ST_NEVILL;
                 }
             } else if (fl >= 0) {
                 failed = true;                                 // label 250
@@ -931,7 +937,13 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
                     if (fine_left <= 0 && fsafe <= 3.0f * p0c * T) { coarse = true; q0ok = false; }
                 }
             }
-        } else if (EXACT && st == ST_REFINE) {
+        } else if (!EXACT && st == ST_REFINE && multi) {
+            // more than one sign change inside the bracket: hand this period to NEVILL, from the scan's bracket
+            // (p0c, cb and their values are still the scan's: this is the first refine pass)
+            nv_ic = 0; nv_nev = 1; nv_m = 1;
+            croot = (p0c + cb) / 2.0f;
+            st = ST_NEVILL;
+        } else if (st == ST_NEVILL) {
             // NEVILL, statement by statement (surfa.f:17-83).  One evaluation per pass: del3 = Delta(c3) has just
             // been computed by every lane of the team (v0); what follows runs up to the next evaluation.
             // SIGN(1., x): the reference's NaNs are positive when they come out of the secular function (negnan
@@ -1841,7 +1853,8 @@ namespace sd {
 
 // working stack per team (+ the ellipticity snapshot slot for teams of >= 4 lanes; allocated for
 // Love too so that one number describes a launch)
-size_t phase_lds_bytes(int Lmax, int G, bool overlap) { return (size_t)((G >= 4 && overlap) ? 2 : 1) * NFW * Lmax * (SD_PHASE_BLOCK / G) * sizeof(float); }
+// NEVILL's table x(12), y(12) per team behind the working stack(s)
+size_t phase_lds_bytes(int Lmax, int G, bool overlap) { return (size_t)(((G >= 4 && overlap) ? 2 : 1) * NFW * Lmax + 24) * (SD_PHASE_BLOCK / G) * sizeof(float); }
 // exact fallback: one working stack per team + NEVILL's table x(12), y(12)
 size_t phase_exact_lds_bytes(int Lmax, int G) { return (size_t)(NFW * Lmax + 24) * (SD_PHASE_BLOCK / G) * sizeof(float); }
 int phase_exact_team(int Lmax)

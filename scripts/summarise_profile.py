@@ -78,8 +78,12 @@ def main(tag):
                 "wave_wait_inst_frac": mean[(k, "SQ_WAIT_INST_ANY")] / wc,
                 "wave_wait_any_frac": mean[(k, "SQ_WAIT_ANY")] / wc,
             }
+    import hashlib
+    with open(os.path.join(ROOT, "pysurfinv_amd", "lib", "libsurfdisp_hip.so"), "rb") as fh:
+        lib_hash = hashlib.sha256(fh.read()).hexdigest()[:16]
     out = {
         "round": tag,
+        "lib_sha256_16": lib_hash,          # bench.py compares it with the library it runs: a stale profile is visible
         "workload": "B=65536 L=10 P=20 Rayleigh c+U, default (point-by-point) scan, one batch in flight",
         "phase_kernel_hbm_bytes_per_launch": per_kernel.get("surfdisp_phase_kernel", {}).get("total"),
         "per_kernel": per_kernel,

@@ -125,7 +125,7 @@ def test_grid_config3_share_of_one_gpu_lockstep(tmp_path):
     assert r["report"]["forward_solves"] == npts * chains * steps + npts
     assert (tr[:, ::steps, 2] == 1).all()                              # first row of every chain is accepted
     # first chain of every point = the initial model, held against THAT point's observations
-    c0 = mb.forward(periods=G["trace/periods"])[0]
+    c0 = mb.forward(periods=G["trace/periods"])[0].double().cpu().numpy()[0]
     ok = np.isfinite(c).all(axis=1)
     mis0 = np.sqrt((((c - c0[None, :]) / u) ** 2).mean(axis=1))
     assert np.allclose(tr[ok, 0, 0], mis0[ok], rtol=2e-3)
