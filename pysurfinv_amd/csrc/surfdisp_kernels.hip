@@ -129,11 +129,84 @@ SD_HD inline void prep_stack(const PrepArgs &A, const int b)
     if (A.nsolved_init) A.nsolved_init[b] = ok ? A.P : 0;      // independent mode: reduced with atomicMin
 }
 
-template <int KIND>
+// Device version: TL lanes per stack (TL = 1 .. 64, a power of two), lane j owns layers j, j + TL, ...  The fp64
+// pow / log of the flattening factors are most of the work and one lane walking 96 layers takes 0.22 ms whatever the
+// batch size, so small batches spread a stack over a whole wavefront.  Bit-identical to prep_stack (which stays as the
+// host reference of tests/hostcheck): the running thickness sum is formed in layer order by every lane for itself
+// (fp32 adds only), and a layer's radii, depths and factors are the same expressions of that sum.
+template <int KIND, int TL>
 __global__ __launch_bounds__(256) void surfdisp_prep_kernel(PrepArgs A)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < A.B) prep_stack<KIND>(A, b);
+    const int Lmax = A.Lmax, B = A.B;
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (int)(tid / TL), j = (int)(tid % TL);
+    const bool valid = b < B;
+    int n = valid ? (A.nlay ? A.nlay[b] : Lmax) : 0;
+    const float *src = A.model + (size_t)(valid ? b : 0) * 5 * Lmax;
+    float *mdl = A.mdl;
+    bool ok = (n >= 2) && (n <= Lmax);
+    if (!ok) n = 0;
+    const float pwr = pwr_of(KIND);
+    const float apw = powr32(R0, pwr);
+    const size_t fs = (size_t)Lmax * B;
+    float hmax = 0.0f, hthick = 0.0f, rhomax = 0.0f, bmax = 0.0f;
+    bool mono = true;
+    float hs = 0.0f;                // running thickness sum over layers < i0 (fp32, layer order: flat1.f:33-37)
+    int i0 = 0;
+    for (int i = j; i < n; i += TL) {
+        for (; i0 < i; ++i0) hs = hs + src[3 * Lmax + i0];
+        const float vp = src[0 * Lmax + i], vs = src[1 * Lmax + i], rho = src[2 * Lmax + i];
+        const float h = src[3 * Lmax + i], qs = src[4 * Lmax + i];
+        if (!(fin(vp) && fin(vs) && fin(rho) && fin(h) && fin(qs)) ||
+            !(vp > 0.0f) || !(rho > 0.0f) || (vs < 0.0f) || (h < 0.0f))
+            ok = false;
+        if (i < n - 1 && h > hmax) hmax = h;
+        if (i > 0 && (vs < src[1 * Lmax + i - 1] || vp < src[0 * Lmax + i - 1])) mono = false;
+        const float r_i = R0 - hs;                           // radius of the top of layer i
+        const float r_n = R0 - (hs + h);                     // ... and of its bottom
+        const float z_i = (i == 0) ? 0.0f : R0 * log32(R0 / r_i);
+        float dif = 0.0f, qqq = 0.0f, dfl = 0.0f;
+        if (i < n - 1) {
+            const float fltd = log32(r_i / r_n);
+            dif = (1.0f / r_n - 1.0f / r_i) * R0 / fltd;
+            const float difr = powr32(r_i, pwr) - powr32(r_n, pwr);
+            qqq = difr / (fltd * apw * pwr);
+            dfl = R0 * log32(R0 / r_n) - z_i;
+            if (!(r_n > 0.0f) || !fin(dif) || !fin(qqq)) ok = false;
+        }
+        const float hsf = R0 / r_i;
+        const float hsr = powr32(1.0f / hsf, pwr);
+        hthick = fmaxf(hthick, dfl);
+        rhomax = fmaxf(rhomax, rho * fmaxf(qqq, hsr));
+        bmax = fmaxf(bmax, 1.06f * vs * fmaxf(dif, hsf));
+        const size_t o = (size_t)i * B + b;
+        mdl[F_VP * fs + o] = vp;   mdl[F_VS * fs + o] = vs;   mdl[F_RHO * fs + o] = rho;
+        mdl[F_H * fs + o] = h;     mdl[F_QS * fs + o] = qs;
+        mdl[F_DIF * fs + o] = dif; mdl[F_QQQ * fs + o] = qqq; mdl[F_DFL * fs + o] = dfl;
+        mdl[F_HSF * fs + o] = hsf; mdl[F_HSR * fs + o] = hsr;
+    }
+    // the stack's verdict and statistics over the lanes of its team
+#pragma unroll
+    for (int d = TL >> 1; d > 0; d >>= 1) {
+        const int ok_o = __shfl_xor((int)ok, d), mono_o = __shfl_xor((int)mono, d);   // every lane shuffles
+        ok = ok && (ok_o != 0);
+        mono = mono && (mono_o != 0);
+        hmax = fmaxf(hmax, __shfl_xor(hmax, d));
+        hthick = fmaxf(hthick, __shfl_xor(hthick, d));
+        rhomax = fmaxf(rhomax, __shfl_xor(rhomax, d));
+        bmax = fmaxf(bmax, __shfl_xor(bmax, d));
+    }
+    if (valid && j == 0) {
+        A.nl[b] = ok ? n : 0;          // 0 => BADMODEL: K1/K2 write zeros
+        if (A.fsafe) A.fsafe[b] = (ok && mono) ? hmax : 1.0e30f;
+        if (A.nsolved_init) A.nsolved_init[b] = ok ? A.P : 0;
+        if (A.ovf) {
+            A.ovf[b] = hthick;
+            A.ovf[(size_t)B + b] = 2.0f * logf(fmaxf(rhomax, 1.0e-30f));
+            A.ovf[2 * (size_t)B + b] = 4.0f * logf(fmaxf(2.0f * bmax * bmax, 1.0e-30f));
+        }
+        if (A.fb_count && b == 0) *A.fb_count = 0;
+    }
 }
 
 // per-period, per-layer working values (calcul.f:112-131 then flat1 with n_flat layers)
@@ -1870,11 +1943,28 @@ hipError_t launch_phase_exact(hipStream_t s, int kind, bool independent, const P
     return kind == 2 ? launch_phase_x<2, false>(s, a) : launch_phase_x<1, false>(s, a);
 }
 
+template <int KIND>
+static void launch_prep_k(hipStream_t s, int TL, const PrepArgs &a)
+{
+    const long threads = (long)a.B * TL;
+    const int grid = (int)((threads + 255) / 256);
+    switch (TL) {
+        case 1:  hipLaunchKernelGGL((surfdisp_prep_kernel<KIND, 1>), dim3(grid), dim3(256), 0, s, a); break;
+        case 2:  hipLaunchKernelGGL((surfdisp_prep_kernel<KIND, 2>), dim3(grid), dim3(256), 0, s, a); break;
+        case 4:  hipLaunchKernelGGL((surfdisp_prep_kernel<KIND, 4>), dim3(grid), dim3(256), 0, s, a); break;
+        case 8:  hipLaunchKernelGGL((surfdisp_prep_kernel<KIND, 8>), dim3(grid), dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((surfdisp_prep_kernel<KIND, 16>), dim3(grid), dim3(256), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((surfdisp_prep_kernel<KIND, 32>), dim3(grid), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((surfdisp_prep_kernel<KIND, 64>), dim3(grid), dim3(256), 0, s, a); break;
+    }
+}
+
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a)
 {
-    const int grid = (a.B + 255) / 256;
-    if (kind == 2) hipLaunchKernelGGL(surfdisp_prep_kernel<2>, dim3(grid), dim3(256), 0, s, a);
-    else           hipLaunchKernelGGL(surfdisp_prep_kernel<1>, dim3(grid), dim3(256), 0, s, a);
+    // lanes per stack: enough wavefronts to give every SIMD about four (262 144 lanes), never more lanes than layers
+    int TL = 1;
+    while (TL < 64 && (long)a.B * TL < 262144L && TL < a.Lmax) TL *= 2;
+    if (kind == 2) launch_prep_k<2>(s, TL, a); else launch_prep_k<1>(s, TL, a);
     return hipGetLastError();
 }
 

@@ -600,3 +600,27 @@ def test_exact_fallback_takes_only_what_it_must(hip, ref_families):
     plan = forward.BatchPlan(m.shape[0], m.shape[2], len(d["periods"]))
     plan.run(m, torch.from_numpy(d["periods"]).cuda(), kind=2, nlay=torch.from_numpy(d["nlay"]).cuda())
     assert plan.fallback_count() == m.shape[0]
+
+
+def test_prep_lanes_per_stack_do_not_change_the_answer(hip):
+    """The prep kernel spreads a stack over 1 .. 64 lanes depending on the batch size (flattening factors: fp64 pow /
+    log per layer).  The same stacks alone (a wavefront per stack) and inside a batch of 70 000 (two lanes per stack)
+    give bit-identical c and U; ragged layer counts and a water layer included."""
+    from pysurfinv_amd import synth
+    per = synth.default_periods(12)
+    L = 21
+    small = synth.synth_models(48, L, seed=77, noise=0.08, monotone=False)
+    small[:8, 1, 0] = 0.0; small[:8, 0, 0] = 1.475; small[:8, 2, 0] = 1.027; small[:8, 4, 0] = 1e-4; small[:8, 3, 0] = 2.0
+    nl_small = np.random.default_rng(1).integers(3, L + 1, 48).astype(np.int32)
+    big = synth.synth_models(70000, L, seed=78)
+    big[:48] = small
+    nl_big = np.full(70000, L, np.int32); nl_big[:48] = nl_small
+    from pysurfinv_amd import _lib
+    _lib.lib().surfdisp_set_team(4)                       # same root-search teams in both launches
+    try:
+        for kind in (2, 1):
+            c0, u0, s0 = hip.forward_batch(small, per, kind, nlay=nl_small)
+            c1, u1, s1 = hip.forward_batch(big, per, kind, nlay=nl_big)
+            assert np.array_equal(c0, c1[:48]) and np.array_equal(u0, u1[:48], equal_nan=True) and np.array_equal(s0, s1[:48])
+    finally:
+        _lib.lib().surfdisp_set_team(0)
