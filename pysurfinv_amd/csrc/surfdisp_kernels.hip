@@ -288,6 +288,20 @@ __device__ __forceinline__ void sinhcosh_sp(float x, float *sh, float *ch)
     *sh = eh - emh;
     *ch = eh + emh;
 }
+// exact fallback kernel: the same, but as the reference forms them - 0.5 (e^x -+ e^-x) from two separate
+// exponentials (surfa.f:267-269; Love: surfa.f:168-172) - so that they overflow to inf at |x| = 88.72 as its
+// exp() does, not ln 2 later: where the secular function leaves the fp32 range decides which "root" the reference
+// returns there
+__device__ __forceinline__ void sinhcosh_ref(float x, float *sh, float *ch)
+{
+    const float L2E_HI = 1.44269502e+00f, L2E_LO = 1.92596299e-08f, LN2 = 6.93147182e-01f;
+    const float t = x * L2E_HI;
+    const float corr = fmaf(x, L2E_LO, fmaf(x, L2E_HI, -t)) * LN2;
+    const float p = __builtin_amdgcn_exp2f(t), q = __builtin_amdgcn_exp2f(-t);
+    const float ep = fmaf(p, corr, p), em = fmaf(q, -corr, q);
+    *sh = 0.5f * (ep - em);
+    *ch = 0.5f * (ep + em);
+}
 __device__ __forceinline__ void sincos_cw(float x, float *sn, float *cs)
 {
     const float TWO_OVER_PI = 6.36619747e-01f;
@@ -357,7 +371,8 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             float sinpr, cosp;
             if (fabsf(ra) < ACCUR) { sinpr = wd; cosp = 1.0f; }
             else if (ra < 0.0f) {
-                float sh, ch; sinhcosh_sp(pm, &sh, &ch);
+                float sh, ch;
+                if constexpr (FACT) sinhcosh_sp(pm, &sh, &ch); else sinhcosh_ref(pm, &sh, &ch);
                 sinpr = sh / ra;
                 cosp = ch;
             } else {
@@ -390,7 +405,8 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         const float qm = wd * rb;
         float rsinp, sinpr, cosp, rsinq, sinqr, cosq;
         if (ra < 0.0f) {                                   // evanescent P, surfa.f:267-269
-            float sh, ch; sinhcosh_sp(pm, &sh, &ch);
+            float sh, ch;
+            if constexpr (FACT) sinhcosh_sp(pm, &sh, &ch); else sinhcosh_ref(pm, &sh, &ch);
             rsinp = -ra * sh;
             sinpr = sh * (FACT ? ira : rcp_nr(ra));
             cosp = ch;
@@ -408,7 +424,8 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             rsinq = rb * sn; sinqr = sn * (FACT ? irb : rcp_nr(rb)); cosq = cs;
             phi += qm;
         } else {
-            float sh, ch; sinhcosh_sp(qm, &sh, &ch);
+            float sh, ch;
+            if constexpr (FACT) sinhcosh_sp(qm, &sh, &ch); else sinhcosh_ref(qm, &sh, &ch);
             rsinq = -rb * sh;
             sinqr = sh * (FACT ? irb : rcp_nr(rb));
             cosq = ch;
@@ -520,7 +537,100 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
     return (start == 1) ? -bb1 : bb1;
 }
 
+// The exact fallback kernel's Rayleigh secular function: DLTAR4 restated statement by statement (surfa.f:193-357),
+// IEEE division and square root, libm-grade exp / sin / cos, no fused multiply-adds - so that every intermediate
+// overflows to inf, and every inf - inf turns NaN, exactly where the reference's does (which decides the "roots" the
+// reference returns next to the overflowed region).  Working stack of that kernel: a in the W_IA2 slot.
+// start = 1 -> dispersion (-bb1); 2 / 3 -> the two ellipticity passes (bb1), combined by the caller (surfa.f:360-363).
+__device__ __noinline__ float delta_rayleigh_ref(const float *wq, const int Lcap, const int S,
+                                                 const int mmax, const float c, const float t, const int start)
+{
+#pragma clang fp contract(off)
+    const float accur = 1.e-8f, accurs = 1.e-8f;
+    const float wvno = 6.28318531f / (c * t);
+    const float csq = c * c;
+    float b1 = (start == 1) ? 1.0f : 0.0f, b2 = (start == 2) ? 1.0f : 0.0f, b3 = (start == 3) ? 1.0f : 0.0f,
+          b4 = 0.0f, b5 = 0.0f;
+    float ra = 0.0f, rb = 0.0f, g = 0.0f, g1 = 0.0f;
+    for (int m = 0; m < mmax; ++m) {
+        const float pm_ = W_IA2(m), sm = W_B(m), rho = W_R(m), d = W_D(m);     // p(m), s(m), rho(m), d(m)
+        const float arga = 1.0f - csq / (pm_ * pm_);
+        ra = sqrtf(fabsf(arga));
+        if (arga > 0.0f) ra = -ra;
+        float a11, a12, a13, a14, a15, a21, a22, a23, a24, a31, a32, a33, a41, a42, a51;
+        if (!(fabsf(sm) > accurs)) {                       // liquid surface layer, surfa.f:216-251
+            const float pm = wvno * ra * d;
+            if (start > 1) continue;
+            const float rhoc = rho * csq;
+            float sinpr, cosp;
+            if (fabsf(ra) < accur || ra == 0.0f) { sinpr = wvno * d; cosp = 1.0f; }
+            else if (ra < 0.0f) { sinpr = (expf(pm) - expf(-pm)) / (2.0f * ra); cosp = 0.5f * (expf(pm) + expf(-pm)); }
+            else { sinpr = sinf(pm) / ra; cosp = cosf(pm); }
+            a11 = cosp; a21 = rhoc * sinpr;
+            a31 = a41 = a51 = a12 = a22 = a32 = a42 = a13 = a23 = a33 = a14 = a24 = a15 = 0.0f;
+        } else {
+            const float argb = 1.0f - csq / (sm * sm);
+            rb = sqrtf(fabsf(argb));
+            if (argb > 0.0f) rb = -rb;
+            g = 2.0f * (sm * sm) / csq;
+            g1 = g - 1.0f;
+            if (m == mmax - 1) break;                      // if(mmax-m) 40,52,40
+            const float rhoc = rho * csq;
+            const float pm = wvno * ra * d, qm = wvno * rb * d;
+            float rsinp, sinpr, cosp, rsinq, sinqr, cosq;
+            if (ra < 0.0f) { rsinp = -ra * 0.5f * (expf(pm) - expf(-pm)); sinpr = -rsinp / (ra * ra); cosp = 0.5f * (expf(pm) + expf(-pm)); }
+            else if (ra == 0.0f) { rsinp = 0.0f; sinpr = wvno * d; cosp = 1.0f; }
+            else { rsinp = ra * sinf(pm); sinpr = rsinp / (ra * ra); cosp = cosf(pm); }
+            if (fabsf(rb) < accur) { rsinq = 0.0f; sinqr = wvno * d; cosq = 1.0f; }
+            else if (rb > 0.0f) { rsinq = rb * sinf(qm); sinqr = rsinq / (rb * rb); cosq = cosf(qm); }
+            else { rsinq = -rb * 0.5f * (expf(qm) - expf(-qm)); sinqr = -rsinq / (rb * rb); cosq = 0.5f * (expf(qm) + expf(-qm)); }
+            const float rr = rsinp * rsinq, ss = sinpr * sinqr, cc = cosp * cosq;
+            const float rs1 = rsinp * cosq, rs2 = sinqr * cosp, rs3 = sinpr * cosq, rs4 = rsinq * cosp;
+            const float gm = 2.0f * g - 1.0f, gs = g * g, g1s = g1 * g1, ccm = 1.0f - cc, gg1 = g * g1;
+            const float rhocs = rhoc * rhoc;
+            const float suu = gs * rr + g1s * ss;
+            a11 = 2.0f * gs - gm;
+            a11 = a11 * cc - suu - 2.0f * gg1;
+            a12 = -(rs1 + rs2) / rhoc;
+            a13 = gm * ccm + g1 * ss + g * rr;
+            a13 = -2.0f * a13 / rhoc;
+            a14 = (rs3 + rs4) / rhoc;
+            a15 = 2.0f * ccm + rr + ss;
+            a15 = a15 / rhocs;
+            a21 = rhoc * (g1s * rs3 + gs * rs4);
+            a22 = cc;
+            a23 = 2.0f * (g * rs4 + g1 * rs3);
+            a24 = sinpr * rsinq;
+            a31 = rhoc * (gg1 * gm * ccm + g1s * g1 * ss + gs * g * rr);
+            a32 = g1 * rs2 + g * rs1;
+            a33 = 1.0f + 2.0f * (2.0f * gg1 * ccm + suu);
+            a41 = -rhoc * (g1s * rs2 + gs * rs1);
+            a42 = rsinp * sinqr;
+            a51 = rhocs * (2.0f * gs * g1s * ccm + gs * gs * rr + g1s * g1s * ss);
+        }
+        const float bb1 = a11 * b1 + a12 * b2 + a13 * b3 + a14 * b4 + a15 * b5;
+        const float bb2 = a21 * b1 + a22 * b2 + a23 * b3 + a24 * b4 - a14 * b5;
+        const float bb3 = a31 * b1 + a32 * b2 + a33 * b3 - 0.5f * a23 * b4 + 0.5f * a13 * b5;
+        const float bb4 = a41 * b1 + a42 * b2 - 2.0f * a32 * b3 + a22 * b4 - a12 * b5;
+        const float bb5 = a51 * b1 - a41 * b2 + 2.0f * a31 * b3 - a21 * b4 + a11 * b5;
+        b1 = bb1; b2 = bb2; b3 = bb3; b4 = bb4; b5 = bb5;
+    }
+    // label 52: the half space (ra, rb, g, g1 of layer mmax from the last trip of the loop)
+    const float pp = W_IA2(mmax - 1), sss = W_B(mmax - 1) * W_B(mmax - 1), ppp = pp * pp;
+    const float rhp = W_R(mmax - 1) * pp;
+    const float gra = g * ra, g1s = g1 * g1, rba = rb - 1.0f / ra;
+    const float h11 = -2.0f * rb * sss / ppp + csq * g1s / ppp / gra;
+    float h12 = rhp * pp;
+    const float h13 = -rb / h12 + g1 / h12 / gra;
+    const float h14 = rb / h12 / gra;
+    const float h15 = rba / rhp / rhp / csq / g;
+    h12 = -1.0f / g / h12;
+    const float bb1 = h11 * b1 + h12 * b2 + 2.0f * h13 * b3 + h14 * b4 + h15 * b5;
+    return (start == 1) ? -bb1 : bb1;
+}
+
 // Love: Thomson-Haskell 2-vector from the half space up, surfa.f:143-179.
+template <bool REFEXP>
 __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, const int S,
                                             const int mmax, const float c, const float T, float &phi)
 {
@@ -547,7 +657,8 @@ __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, con
         float yv, z, cosq;
         if (rb < 0.1e-20f || c == bm) { yv = -wvno * d; z = 0.0f; cosq = 1.0f; }
         else if (c < bm) {
-            float sh, ch; sinhcosh_sp(q, &sh, &ch);
+            float sh, ch;
+            if constexpr (REFEXP) sinhcosh_ref(q, &sh, &ch); else sinhcosh_sp(q, &sh, &ch);
             yv = sh * rcp_nr(rb);
             z = -rb * rb * yv;
             cosq = ch;
@@ -570,6 +681,42 @@ __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, con
         m -= 2;
     }
     if (m == 0) step(A);
+    return -tt;
+}
+
+// ... and its Love secular function: DLTAR1 statement by statement (surfa.f:143-179), same rules.
+__device__ __noinline__ float delta_love_ref(const float *wq, const int Lcap, const int S,
+                                             const int mmax, const float c, const float t)
+{
+#pragma clang fp contract(off)
+    const float wvno = 6.2831853f / (c * t);
+    float covb = c / W_B(mmax - 1);
+    float h = W_R(mmax - 1) * W_B(mmax - 1) * W_B(mmax - 1);
+    float rb = sqrtf(fabsf(covb * covb - 1.0f));
+    float ut = 1.0f, tt = h * rb;
+    for (int m = mmax - 2; m >= 0; --m) {
+        const float bm = W_B(m);
+        if (bm == 0.0f) continue;
+        covb = c / bm;
+        rb = sqrtf(fabsf(covb * covb - 1.0f));
+        h = W_R(m) * bm * bm;
+        const float d = W_D(m);
+        const float q = -wvno * d * rb;
+        float y, z, cosq;
+        if (rb < 0.1e-20f || c - bm == 0.0f) { y = -wvno * d; z = 0.0f; cosq = 1.0f; }
+        else if (c - bm < 0.0f) {
+            const float exqp = expf(q), exqm = 1.0f / exqp;
+            y = (exqp - exqm) / (2.0f * rb);
+            z = -rb * rb * y;
+            cosq = (exqp + exqm) / 2.0f;
+        } else {
+            const float sinq = sinf(q);
+            y = sinq / rb; z = rb * sinq; cosq = cosf(q);
+        }
+        const float eut = cosq * ut - y * tt / h;
+        const float ett = h * z * ut + cosq * tt;
+        ut = eut; tt = ett;
+    }
     return -tt;
 }
 
@@ -716,7 +863,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
             // the reciprocals are this kernel's own helper values (not the reference's): v_rcp + one Newton
             // step (<= 1 ulp) instead of three IEEE divisions
             W_IR(i) = rcp_nr(v.rho); W_B(i) = v.b; W_R(i) = v.rho; W_D(i) = v.d;
-            W_IA2(i) = rcp_nr(v.a * v.a);
+            W_IA2(i) = (EXACT && KIND == 2) ? v.a : rcp_nr(v.a * v.a);       // exact kernel: a itself (delta_rayleigh_ref)
             W_IB2(i) = (v.b > 0.0f) ? rcp_nr(v.b * v.b) : 0.0f;
         }
         __builtin_amdgcn_wave_barrier();
@@ -823,8 +970,9 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         }
         float val = 0.0f, phj = 0.0f;
         if (eval) {
-            if (KIND == 2) val = delta_rayleigh<!EXACT>(wl, Lcap, S, mmj, cj, Tl, start, phj);
-            else           val = delta_love(wl, Lcap, S, mmj, cj, Tl, phj);
+            if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, Lcap, S, mmj, cj, Tl, start)
+                                       : delta_rayleigh<true>(wl, Lcap, S, mmj, cj, Tl, start, phj);
+            else           val = EXACT ? delta_love_ref(wl, Lcap, S, mmj, cj, Tl) : delta_love<false>(wl, Lcap, S, mmj, cj, Tl, phj);
         }
         // ---------------------------------------------------------------- team-level decisions
         const int lm1 = (lane + 63) & 63;

@@ -28,6 +28,11 @@ while time.time() < T_END:
     if sed:                                                 # soft sediments over rock (synth.sediment_models)
         model = synth.sediment_models(B, L, seed=int(rng.integers(1 << 30)), noise=noise,
                                       total_thickness=float(rng.choice([30., 60., 120., 200., 400.])))
+    ovf = os.environ.get("SOAK_FAMILY") == "overflow"
+    if ovf:                                                 # two to five layers of 60-250 km: the fp32 secular function overflows
+        L = int(rng.integers(2, 6))
+        model = synth.synth_models(B, L, seed=int(rng.integers(1 << 30)), noise=noise, monotone=mono,
+                                   total_thickness=float(rng.uniform(60., 250.)) * L)
     nlay = None
     if rng.random() < 0.3 and L > 3:
         nlay = rng.integers(2, L + 1, B).astype(np.int32)
@@ -37,6 +42,8 @@ while time.time() < T_END:
         per = np.linspace(rng.uniform(4, 12), rng.uniform(40, 120), P).astype(np.float32)
     if sed:
         per = np.sort(rng.uniform(0.3, 30.0, P)).astype(np.float32)
+    if ovf:
+        per = np.sort(rng.uniform(2.5, 40.0, P)).astype(np.float32)
     team = int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64]))
     _lib.lib().surfdisp_set_team(team)
     c, u, st = forward.forward_batch(model, per, kind, nlay=nlay)

@@ -490,10 +490,14 @@ def test_soak_family_fixtures(hip, ref_families, family):
 @pytest.mark.parametrize("wave", ["R", "L"])
 def test_wild_family_terminates_and_mostly_agrees(hip, ref_families, wave):
     """Anything monotone: layers of 0.1-5 km/s, 10 m - 50 km thick, periods 0.1-300 s.  Kilometres of 0.1 km/s material
-    at 0.15 s are hundreds of wavelengths: the fp32 secular function is noise or NaN over most of the scan, both
-    implementations bracket rounding-decided sign changes, and which one comes first differs (the reference's own
-    U is NaN at a fifth of these entries).  What must hold: termination, finite-or-zero phase velocities, the
-    failure cascade (zeros only at the tail), and agreement on the well-posed majority."""
+    at 0.15 s are hundreds of wavelengths: the fp32 secular function overflows or is rounding noise over most of the
+    scan, and the reference brackets rounding-decided sign changes (its own U is NaN at a fifth of these entries).
+    Nearly all of these stacks go through the exact fallback kernel (the reference's arithmetic restated statement by
+    statement), which reproduces most of that: measured (profiles/r02a/parity_table.txt) Rayleigh - every zero
+    pattern, 96 % of the phase velocities within 1e-4; Love - 94-97 % of the zero patterns, 75-82 % of the values
+    (its modes crowd far below the 0.01 km/s walk in the slow layers, and an early period that lands on another
+    overtone hands a different start value to every later one).  Also: termination, finite-or-zero outputs, the
+    failure cascade (zeros only at the tail)."""
     d = ref_families[f"wild_{wave}"]
     c, u, st = hip.forward_batch(d["model"], d["periods"], d["kind"], nlay=d["nlay"])
     assert np.isfinite(c).all() and (c >= 0).all()
@@ -501,12 +505,9 @@ def test_wild_family_terminates_and_mostly_agrees(hip, ref_families, wave):
     assert (nz[:, :-1] | ~nz[:, 1:]).all()                       # once a period failed, all later ones are zero
     both = nz & (d["c"] > 0)
     e = np.abs(c[both].astype(np.float64) / d["c"][both] - 1)
-    # measured (profiles/r02a/parity_table.txt): Rayleigh median 9e-7, 79 % of the entries within 1e-4 (94 % at T >= 3 s);
-    # Love 49 % - its modes crowd far below the 0.01 km/s walk in the slow layers, brackets hold several roots, and
-    # an early period that lands on another overtone hands a different start value to every later one
-    assert (e < 1e-4).mean() > (0.7 if wave == "R" else 0.4)
-    if wave == "R":
-        assert np.median(e) < 1e-5
+    same = ((c > 0) == (d["c"] > 0)).all(axis=1).mean()
+    assert np.median(e) < 1e-5
+    assert (e < 1e-4).mean() > (0.9 if wave == "R" else 0.7) and same >= (0.97 if wave == "R" else 0.9)
 
 
 @pytest.mark.parametrize("team", [2, 4, 8, 64])
