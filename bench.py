@@ -185,12 +185,14 @@ def workload_forward(rt, args):
     per_np = synth.default_periods(NPER)
     model = torch.from_numpy(synth.synth_models(B_PER_GPU, NLAY, seed=rank)).to(dev)
     per = torch.from_numpy(per_np).to(dev)
-    # Two batches in flight on two HIP streams: each batch is ONE wave of work for the chip (65 536 teams, fewer
-    # than the lanes it holds), its wavefronts finish at different times, and a second independent batch fills the
-    # SIMD slots the first one vacates.  Same work per step; the one-batch-in-flight rate is reported beside it.
-    # With a second batch in flight the launches carry SURFDISP_PIPELINED (lanes per stack chosen for both batches);
-    # results are identical for every team size (tests/test_gpu_parity.py).
-    NFLIGHT = int(os.environ.get("BENCH_IN_FLIGHT", "2"))
+    # Three batches in flight on three HIP streams: one batch is ONE wave of work for the chip (65 536 teams, fewer
+    # than the lanes it holds), its wavefronts finish at different times, and the next independent batches fill the
+    # SIMD slots it vacates (measured, scripts/sweep_inflight.sh: 26.8 / 28.8 / 30.9 M solves/s with 1 / 2 / 3 in
+    # flight).  Same work per step; the one-batch-in-flight rate is reported beside it.  With more than one batch in
+    # flight the launches carry SURFDISP_PIPELINED (lanes per stack chosen for the batches together); results are
+    # identical for every team size (tests/test_gpu_parity.py).
+    NFLIGHT = int(os.environ.get("BENCH_IN_FLIGHT", "3"))
+    HINT = os.environ.get("BENCH_PIPELINED_HINT", "1") == "1"         # development: launch without the hint
     plans = [forward.BatchPlan(B_PER_GPU, NLAY, NPER, device=dev) for _ in range(NFLIGHT)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NFLIGHT)]
     ring = forward.EventRing(args.steps)       # HIP events recorded on the launch stream, read after the sync
@@ -199,7 +201,7 @@ def workload_forward(rt, args):
         for i in range(n):
             with torch.cuda.stream(streams[i % nflight]):
                 plans[i % nflight].run(model, per, kind=KIND, events=ring.slot(i) if record else None,
-                                       pipelined=nflight > 1, fast_scan=fast_scan)
+                                       pipelined=(nflight > 1) and HINT, fast_scan=fast_scan)
 
     steps(max(args.warmup, NFLIGHT), NFLIGHT)
     rt.barrier()

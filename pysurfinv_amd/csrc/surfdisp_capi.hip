@@ -25,6 +25,7 @@ struct EnvKnobs {
     float phimax = 0.7853982f;    // SURFDISP_SCAN_PHASE (fast scan only; developer knob)
     bool fastscan = false;        // SURFDISP_FASTSCAN=1: opt every call of the process into the heuristic scan
     int device = 0;               // SURFDISP_DEVICE (fast_surf_)
+    int balance = -1;             // SURFDISP_BALANCE (developer knob): wavefront priority by progress, -1 = automatic
     EnvKnobs()
     {
         if (const char *e = getenv("SURFDISP_TEAM")) team = atoi(e);
@@ -34,6 +35,7 @@ struct EnvKnobs {
         if (const char *e = getenv("SURFDISP_SCAN_PHASE")) phimax = (float)atof(e);
         if (const char *e = getenv("SURFDISP_FASTSCAN")) fastscan = atoi(e) != 0;
         if (const char *e = getenv("SURFDISP_DEVICE")) device = atoi(e);
+        if (const char *e = getenv("SURFDISP_BALANCE")) balance = atoi(e);
     }
 };
 const EnvKnobs &knobs() { static const EnvKnobs k; return k; }
@@ -226,7 +228,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     const float wtol = kn.refine_wtol, atol = kn.refine_atol, phimax = kn.phimax;
     sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, phase_only ? nullptr : w.ratio, w.nsolved, status, wtol, atol,
                      fastscan ? 1 : 0, w.fsafe, (!phase_only && use_overlap(Lmax, G)) ? 1 : 0, phimax,
-                     w.ovf, w.fb_count, w.fb_list, pipelined ? 0 : 1};
+                     w.ovf, w.fb_count, w.fb_list, kn.balance >= 0 ? kn.balance : (pipelined ? 0 : 1)};
 #ifdef SD_WAVECLOCK
     ph.wclk = reinterpret_cast<unsigned long long *>(g_dbg.load(std::memory_order_relaxed));
 #endif

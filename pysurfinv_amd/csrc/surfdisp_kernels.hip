@@ -742,10 +742,6 @@ __device__ __forceinline__ int drop_layers(const float *wq, const int Lcap, cons
 }
 
 // ================================================================================== K1: phase
-#ifdef SD_STATS
-// developer build (make stats): pass counters of the root search, read through surfdisp_stats() in this file
-__device__ unsigned long long g_stats[24];
-#endif
 enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3, ST_NEVILL = 4 };
 
 
@@ -993,9 +989,6 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         // half space at the coarse points around it, and ln|Delta| bends so little at BOTH ends of the
         // interval that no pair of roots can hide in it.  Anything else is rescanned point by point.
         bool uncert = false, back0 = false;
-#ifdef SD_STATS
-        int why = 0;
-#endif
         if (fastok) {
         const int ln1 = (lane + 1) & 63, lm2 = (lane + 62) & 63;
         const float nx_d = __shfl(val, ln1), sp_d = __shfl(val, lm2);
@@ -1047,13 +1040,6 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
             // lane 0 also holds the right end of the previous pass's last interval (q0, p0): if that fails the
             // rescan starts at q0
             back0 = (j == 0) && q0ok && (cross ? !okphi : !oklog_b);
-#ifdef SD_STATS
-            {
-                const bool mmch = !((pmm == mmj) && (!has_next || mmj == nx_mm) && (!has_pp || pp_mm == pmm));
-                const bool lg = (has_next && nx_same && !logsd_ok(pd, val, nx_d)) || (has_pp && !oklog_b);
-                why = near_hs ? 3 : mmch ? 4 : lg ? 6 : !okphi ? 7 : !oke ? 8 : uncert ? 9 : 0;
-            }
-#endif
         }
         }
         const bool ev = searching && (cross || guard || uncert);
@@ -1066,19 +1052,6 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         const int e_pmm = __shfl(pmm, src);
         const int l_mm = __shfl(mmj, tbase + G - 1);
         const int e_cross = __shfl((int)cross, src);
-#ifdef SD_STATS
-        {
-            auto cnt = [&](int idx, bool pred) {
-                const unsigned long long m = __ballot(pred && j == 0);
-                if (lane == 0 && m) atomicAdd(&g_stats[idx], (unsigned long long)__popcll(m));
-            };
-            const int e_why = __shfl(cross ? 1 : (guard ? 2 : why), src);
-            const bool cs = fastok && coarse && st == ST_SCAN;
-            cnt(0, st == ST_SCAN); cnt(1, st == ST_REFINE); cnt(2, st == ST_ELLIP); cnt(5, cs); cnt(6, cs && fl >= 0 && !e_cross);
-            for (int r = 1; r <= 9; ++r) cnt(8 + r, cs && fl >= 0 && e_why == r);
-            cnt(18, cs && fl == tbase && __shfl((int)back0, tbase) != 0);
-        }
-#endif
         const int t_back0 = __shfl((int)back0, tbase);
         const int lastl = tbase + G - 1;
         const float l_c = __shfl(cj, lastl), l_d = __shfl(val, lastl);
@@ -1280,9 +1253,6 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
                 solved = true;
             }
         }
-#ifdef SD_STATS
-        { const unsigned long long m = __ballot(solved && j == 0); if (lane == 0 && m) atomicAdd(&g_stats[4], (unsigned long long)__popcll(m)); }
-#endif
         if (!EXACT && defer) {
             if (j == 0) A.fb_list[atomicAdd(A.fb_count, 1)] = (int)tg;
             defer = false; st = ST_DONE; ell_pend = false; solved = false; failed = false; fatal = false;
@@ -2144,12 +2114,3 @@ hipError_t launch_group(hipStream_t s, int kind, const GroupArgs &a)
 
 }  // namespace sd
 
-#ifdef SD_STATS
-extern "C" void surfdisp_stats(unsigned long long *out, int reset)
-{
-    unsigned long long z[24] = {0};
-    if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(sd::g_stats), z, sizeof(z)); return; }
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(sd::g_stats), sizeof(z));
-}
-#endif

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box, developer build `make -C pysurfinv_amd/csrc waveclock`: lifetimes of the root-search wavefronts of one
 bench batch (B = 65536 x L10 x P20 Rayleigh) - how much of the kernel's duration the machine is full.
-    SURFDISP_LIB_PATH=pysurfinv_amd/lib/libsurfdisp_wclk.so python scripts/dev_waveclock.py [team] [B]"""
+    SURFDISP_LIB_PATH=pysurfinv_amd/lib/libsurfdisp_wclk.so python scripts/waveclock.py [team] [B]"""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
