@@ -435,9 +435,10 @@ def main():
         line = workload_forward(rt, args)
         if args.workload == "all":
             extra = {}
-            for name, fn, kw in (("grid", workload_grid, dict(steps=10, warmup=2)),
-                                 ("mcmc", workload_mcmc, dict(steps=60)),
-                                 ("c5", workload_c5, dict(steps=3, warmup=1))):
+            legs = {"grid": (workload_grid, dict(steps=10, warmup=2)), "mcmc": (workload_mcmc, dict(steps=60)),
+                    "c5": (workload_c5, dict(steps=3, warmup=1))}
+            for name in os.environ.get("BENCH_LEGS", "mcmc,grid,c5").split(","):       # development: subset / order
+                fn, kw = legs[name]
                 try:
                     extra[name] = fn(rt, args, **kw)
                 except Exception as e:                          # a side leg must never cost the headline line
