@@ -9,8 +9,9 @@
  *                                                                 fast_surf_src/fast_surf.pyf:6-19
  *   - call sites      models.py:27 (_calForward), senskernel.py:188 (SensKernelPert._forward)
  *
- * Plain pointers and sizes only; no torch / C++ types.  All entry points are reentrant
- * (the reference is not: COMMON state, fast_surf.f:48-71).
+ * Plain pointers and sizes only; no torch / C++ types.  The solve entry points keep no state between
+ * calls (the reference does: COMMON blocks, fast_surf.f:48-71) and may be called from several threads;
+ * surfdisp_set_team and the environment knobs are process-wide tuning state.
  *
  * Conventions kept from the reference:
  *   - argument order (Vp, Vs, rho, h, 1/Qs)                       fast_surf.f:2-5,44-45
@@ -70,10 +71,11 @@ enum {
     SURFDISP_PARTIAL    = 1,   /* bracketing failed at period k>1: c,U of periods k..P are 0 (calcul.f:203,218-219) */
     SURFDISP_NOROOT     = 2,   /* bracketing failed at the first period: everything 0 (calcul.f:203-212) */
     SURFDISP_BADMODEL   = 4,   /* nlay < 2, nlay > Lmax, or non-finite input: everything 0 */
-    SURFDISP_NUMERIC    = 8    /* the secular function left the fp32 range (NaN) during the root search (very
-                                * thick layers at short periods).  The reference's NEVILL then exhausts its 50
-                                * cycles and the call returns nothing (surfa.f:17-27, calcul.f:172-189):
-                                * everything 0, also the periods already solved */
+    SURFDISP_NUMERIC    = 8    /* a root at or above 16 km/s: one fp32 ulp (1.9e-6) exceeds NEVILL's 1e-6 bracket
+                                * tolerance, the reference exhausts its 50 cycles and the call returns nothing
+                                * (surfa.f:17-27, calcul.f:172-189): everything 0, also the periods already solved.
+                                * (A secular function that overflows fp32 is not an error - the reference returns
+                                * the edge of the overflowed region as a root and so does this library.) */
 };
 
 /* return codes */

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Grid-of-points inversion ("model3D" flow) on the GPUs of one node, one rank per GPU:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        scripts/run_grid.py --input grid.npz --setting setting.json --outdir mcdata [--chains 50 --chainL 1000]
+    python scripts/run_grid.py --synthetic 64 --outdir mcdata            # one GPU, synthetic observations
+
+``--input``: npz with lons[n], lats[n], periods[P], c_obs[n, P], uncer[n, P] (NaN = masked period).
+``--setting``: the reference's model setting as JSON (``models.py:42-51``; default: the continental example of
+``bench.py``).  Every rank inverts its block of points (``pysurfinv_amd.grid.run_grid``), writes
+``{outdir}/{lon}_{lat}.npz`` with the reference's keys - what ``Model3D.loadInvDir`` (``model3D.py:36-57``) reads - and
+rank 0 writes ``{outdir}/summaries.npz``: one row per point of what ``PostPoint`` derives (minimum-misfit and average
+accepted model, misfits, predicted curve), gathered over RCCL.  ``--backend gloo --device cpu`` needs a ``forward``
+callable and is for tests only (the product path has no CPU solver).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--input")
+    ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic points instead of --input")
+    ap.add_argument("--setting")
+    ap.add_argument("--outdir", required=True)
+    ap.add_argument("--chains", type=int, default=50)
+    ap.add_argument("--chainL", type=int, default=1000)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--fast-scan", action="store_true", help="opt into the heuristic scan (SURFDISP_FASTSCAN)")
+    args = ap.parse_args()
+
+    import torch
+    import bench
+    from pysurfinv_amd import grid
+    from pysurfinv_amd.layers_batch import Model1DBatch
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+    setting = json.load(open(args.setting)) if args.setting else bench.MCMC_SETTING
+    mb = Model1DBatch(setting, device=dev)
+    if args.input:
+        z = np.load(args.input)
+        lons, lats, periods, c_obs, uncer = z["lons"], z["lats"], z["periods"], z["c_obs"], z["uncer"]
+    else:
+        n = max(1, args.synthetic)
+        class _RT:                                     # the synthetic observations of bench.py's grid leg
+            pass
+        rt = _RT(); rt.torch, rt.dev, rt.rank = torch, dev, 0
+        _, c_obs, uncer = bench._mcmc_setup(rt, n, args.chains)
+        periods = np.asarray(bench.MCMC_PERIODS, float)
+        lons, lats = 230.0 + 0.5 * (np.arange(n) % 64), 40.0 + 0.5 * (np.arange(n) // 64)
+    r = grid.run_grid(mb, lons, lats, periods, c_obs, uncer, args.chains, args.chainL, outdir=args.outdir,
+                      rank=rank, world=world, device=str(dev), seed=args.seed, fast_scan=args.fast_scan, keep_tracks=False)
+    if rank == 0:
+        os.makedirs(args.outdir, exist_ok=True)
+        np.savez_compressed(os.path.join(args.outdir, "summaries.npz"), summaries=r["summaries"], columns=np.array(r["columns"]),
+                            lons=lons, lats=lats, periods=periods)
+        rep = dict(r["report"]); rep.update(n_gpus=world, elapsed_write_rank0=r["elapsed_write"])
+        print(json.dumps(rep), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
