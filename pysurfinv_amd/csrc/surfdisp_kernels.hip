@@ -880,6 +880,19 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         return !(lnmag < 84.0f);                                           // also when c_lo or T is not positive
     };
 
+    // Layer dropping (surfa.f:94-105) picks the first layer at which the thickness summed over the layers with
+    // c < b exceeds 4 c T.  When the thickness of ALL n layers in the working stack (stale deep ones included) stays
+    // below 4 c T at the period's lowest trial velocity, no trial of the period can drop anything: mmax = n without
+    // walking the stack (three quarters of the bench workload's periods).  1e-5 covers the rounding of the partial sums.
+    bool nodrop = false;
+    auto no_drop_possible = [&](float c_lo) -> bool {
+        float dsum = 0.0f;
+        for (int i = j; i < n; i += G) dsum += W_D(i);
+#pragma unroll
+        for (int d = G >> 1; d > 0; d >>= 1) dsum += __shfl_xor(dsum, d);
+        return dsum * 1.00001f <= FACT * c_lo * T;
+    };
+
     if (st != ST_DONE) {
         T = A.per[k];
         // clear the slot (a new process sees zeroed COMMON /d/)
@@ -896,6 +909,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         if (water) p0c = 0.5f;
         first = true;
         defer = entry_overflow_risk(p0c);
+        nodrop = no_drop_possible(p0c);
     }
 
     int wprio = -1;
@@ -937,7 +951,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
 #pragma unroll
                 for (int i = 0; i < G; ++i) if (i < nadd) cj = cj + DC;
             }
-            mmj = drop_layers(wq, Lcap, S, n, cj, T);          // idrop=0 before every scan trial
+            mmj = nodrop ? (n < 2 ? 2 : n) : drop_layers(wq, Lcap, S, n, cj, T);   // idrop=0 before every scan trial
         } else if (st == ST_NEVILL) {
             cj = croot; mmj = mm_frozen;                       // NEVILL's c3, idrop = 1
         } else if (st == ST_REFINE) {
@@ -1277,6 +1291,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
                 coarse = false; fine_left = 1; q0ok = false;
                 st = ST_SCAN;
                 defer = entry_overflow_risk(p0c);              // acted on at the end of the next pass
+                nodrop = no_drop_possible(p0c);
             }
         }
         if (failed) {
