@@ -107,6 +107,7 @@ SD_HD inline void prep_stack(const PrepArgs &A, const int b)
             const float hsr = powr32(1.0f / hsf, pwr);
             // 6 % on the velocities for the attenuation correction (1 + qs ln(1/T)/pi, calcul.f:122-126)
             hthick = fmaxf(hthick, dfl);
+            if (i > 0 && !(fabsf(vs) > ACCUR)) hthick = 1.0e30f;
             rhomax = fmaxf(rhomax, rho * fmaxf(qqq, hsr));
             bmax = fmaxf(bmax, 1.06f * vs * fmaxf(dif, hsf));
             const size_t o = (size_t)i * B + b;
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256) void surfdisp_prep_kernel(PrepArgs A)
         const float hsf = R0 / r_i;
         const float hsr = powr32(1.0f / hsf, pwr);
         hthick = fmaxf(hthick, dfl);
+        if (i > 0 && !(fabsf(vs) > ACCUR)) hthick = 1.0e30f;   // a liquid layer below the top: exact kernel (entry_overflow_risk)
         rhomax = fmaxf(rhomax, rho * fmaxf(qqq, hsr));
         bmax = fmaxf(bmax, 1.06f * vs * fmaxf(dif, hsf));
         const size_t o = (size_t)i * B + b;
@@ -347,7 +349,10 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
     // is unrolled by two over alternating register sets (no rotation moves between iterations).
     struct Lyr { float sv, rho, d, ia2, ib2, ir; };
     auto load = [&](int m) -> Lyr { return {W_B(m), W_R(m), W_D(m), W_IA2(m), W_IB2(m), W_IR(m)}; };
-    auto step = [&](const Lyr &y) {
+    // first_tag: only the TOP layer may be liquid in the production kernel (a stack with a liquid layer further down
+    // is handed to the exact fallback kernel by the prep kernel's statistics), so the test is made once per evaluation
+    auto step = [&](const Lyr &y, auto first_tag) {
+        constexpr bool MAYBE_LIQUID = decltype(first_tag)::value || !FACT;
         const float sv = y.sv, rho = y.rho, d = y.d, ia2 = y.ia2, ib2 = y.ib2, irho = y.ir;
         const float arga = fmaf(-csq, ia2, 1.0f);                    // 1 - c^2/a^2, surfa.f:211
         // production kernel: ra and 1/ra from ONE v_rsq_f32 (1 ulp; ra = x rsq(x) to ~1.5 ulp) instead of
@@ -364,7 +369,7 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         }
         const float wd = wvno * d;
         const float rhoc = rho * csq;
-        if (!(fabsf(sv) > ACCUR)) {
+        if (MAYBE_LIQUID && !(fabsf(sv) > ACCUR)) {
             // liquid surface layer, surfa.f:216-251 (skipped entirely in the ellipticity passes)
             if (start != 1) return;
             const float pm = wd * ra;
@@ -499,16 +504,22 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
     const int last = mmax - 1;                                       // the half space
     Lyr A = load(0);
     int m = 0;
+    if (last >= 1) {                                                 // layer 0: the one that may be water
+        const Lyr Bq = load(1);
+        step(A, std::true_type{});
+        A = Bq;
+        m = 1;
+    }
     while (m + 2 <= last) {
         const Lyr Bq = load(m + 1);
-        step(A);
+        step(A, std::false_type{});
         A = load(m + 2);
-        step(Bq);
+        step(Bq, std::false_type{});
         m += 2;
     }
     if (m < last) {
         const Lyr Bq = load(m + 1);
-        step(A);
+        step(A, std::false_type{});
         A = Bq;
     }
     const float n_sv = A.sv, n_ir = A.ir, n_ia2 = A.ia2, n_ib2 = A.ib2;   // layer mmax-1

@@ -625,3 +625,22 @@ def test_prep_lanes_per_stack_do_not_change_the_answer(hip):
             assert np.array_equal(c0, c1[:48]) and np.array_equal(u0, u1[:48], equal_nan=True) and np.array_equal(s0, s1[:48])
     finally:
         _lib.lib().surfdisp_set_team(0)
+
+
+def test_liquid_layer_below_the_top_goes_through_the_exact_kernel(hip):
+    """The production Rayleigh recursion tests for a liquid layer only at the top (water); a stack with Vs = 0 further
+    down - the reference applies its liquid-layer matrix there too (surfa.f:216-251) - is re-solved by the exact
+    fallback kernel and still equals the oracle."""
+    import torch
+    from oracle import cport
+    from pysurfinv_amd import synth, forward
+    per = synth.default_periods(10)
+    m = synth.synth_models(32, 8, seed=12)
+    m[:16, 1, 2] = 0.0                                    # a liquid layer inside half of the stacks
+    c, u, st = hip.forward_batch(m, per, 2)
+    co, uo, so = cport.forward_batch(m, per, 2, nthreads=4)
+    assert np.array_equal(c > 0, co > 0)
+    assert relerr(c, co) < TOL_C
+    plan = forward.BatchPlan(32, 8, 10)
+    plan.run(torch.from_numpy(m).cuda(), torch.from_numpy(per).cuda(), kind=2)
+    assert plan.fallback_count() == 16
