@@ -321,27 +321,38 @@ __device__ __forceinline__ void sincos_cw(float x, float *sn, float *cs)
     *cs = ((n + 1) & 2) ? -c0 : c0;
 }
 
-// Rayleigh: Dunkin compound-matrix recursion, surfa.f:193-357.  start = 1 -> dispersion
-// (returns -bb1, surfa.f:357); start = 2/3 -> the two ellipticity passes (returns bb1, surfa.f:360-363).
-// Same formulas as the reference; divisions folded into three reciprocals per layer and the
-// c-independent 1/a^2, 1/b^2 taken from LDS.
-// FACT = true : the layer matrix is applied in factorised form (below) - the production root search;
-// FACT = false: the fifteen entries are formed and multiplied out exactly as the reference does (surfa.f:289-330),
-//               so that overflow to inf / NaN happens where the reference's does - the exact fallback kernel.
-template <bool FACT>
+// Rayleigh, production kernel: Dunkin's compound-matrix recursion (surfa.f:193-357) in a form built for the VALU.
+// start = 1 -> dispersion (returns -bb1, surfa.f:357); start = 2 / 3 -> the two ellipticity passes (bb1, surfa.f:360-363).
+//
+// The layer's compound matrix is never formed.  Its fifteen entries (surfa.f:289-320) are linear in the nine products
+// (cosp, rsinp, sinpr) x (cosq, rsinq, sinqr); collecting the update by product instead of by entry gives, exactly
+// (algebraic identity, checked in fp64 to 3e-14; same fp32 error against an fp64 evaluation as the entry-by-entry form),
+//   h = (b2, b3, b4)/rhoc, h5 = b5/rhoc^2,  u1 = g^2 b1 + 2g h3 - h5,  u2 = g1^2 b1 + 2g1 h3 - h5,
+//   E1 = rsinp (rsinq u1 + cosq h2) - cosp rsinq h4 + (1 - cosp cosq) u2,
+//   E2 = sinpr (sinqr u2 - cosq h4) + cosp sinqr h2 + (1 - cosp cosq) u1,
+//   b1' = b1 - E1 - E2,  h3' = h3 + g E1 + g1 E2,  h5' = h5 + g^2 E1 + g1^2 E2,
+//   h2' = cosp (cosq h2 + rsinq u1) + sinpr (rsinq h4 + cosq u2),
+//   h4' = rsinp (sinqr h2 - cosq u1) - cosp (sinqr u2 - cosq h4).
+// The state is carried as (b1, h2..h5): going from layer m to m+1 only rescales it by rho_m/rho_(m+1) (rhoc = rho c^2
+// and c is the same), and the half-space row is applied to rhoc h.  ~40 operations per layer instead of ~100.
+// Vertical wavenumbers ra, rb and their reciprocals come from ONE v_rsq_f32 each; sinh/cosh from two v_exp_f32.
+// (The reference's own arithmetic, statement by statement, is delta_rayleigh_ref below: the exact fallback kernel.)
 __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap, const int S,
                                                 const int mmax, const float c, const float T,
                                                 const int start, float &phi)
 {
     // phi: vertical phase sum_i k d_i sqrt(c^2/v_i^2 - 1) over the layers (and wave types) that are oscillatory
-    // at c -- the WKB mode counter the certified scan bounds between two coarse points (free: pm and qm are
+    // at c -- the WKB mode counter the opt-in fast scan bounds between two coarse points (free: pm and qm are
     // the recursion's own arguments)
     phi = 0.0f;
     const float wvno = 6.28318531f * rcp_nr(c * T);                 // <= 1 ulp: like a 6e-8 change of the period
     const float csq = c * c;
     const float icsq = rcp_nr(csq);
-    float b1 = (start == 1) ? 1.0f : 0.0f, b2 = (start == 2) ? 1.0f : 0.0f,
-          b3 = (start == 3) ? 1.0f : 0.0f, b4 = 0.0f, b5 = 0.0f;
+    // start vector (1,0,0,0,0) / e2 / e3 in the scale of the top layer
+    const float irhoc0 = (start == 1) ? 0.0f : W_IR(0) * icsq;
+    float b1 = (start == 1) ? 1.0f : 0.0f, h2 = (start == 2) ? irhoc0 : 0.0f,
+          h3 = (start == 3) ? irhoc0 : 0.0f, h4 = 0.0f, h5 = 0.0f;
+    float rho_prev = 0.0f;
     // software pipeline: layer m+1's six LDS values are in flight while layer m is computed.  The loop
     // is unrolled by two over alternating register sets (no rotation moves between iterations).
     struct Lyr { float sv, rho, d, ia2, ib2, ir; };
@@ -349,32 +360,27 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
     // first_tag: only the TOP layer may be liquid in the production kernel (a stack with a liquid layer further down
     // is handed to the exact fallback kernel by the prep kernel's statistics), so the test is made once per evaluation
     auto step = [&](const Lyr &y, auto first_tag) {
-        constexpr bool MAYBE_LIQUID = decltype(first_tag)::value || !FACT;
-        const float sv = y.sv, rho = y.rho, d = y.d, ia2 = y.ia2, ib2 = y.ib2, irho = y.ir;
-        const float arga = fmaf(-csq, ia2, 1.0f);                    // 1 - c^2/a^2, surfa.f:211
-        // production kernel: ra and 1/ra from ONE v_rsq_f32 (1 ulp; ra = x rsq(x) to ~1.5 ulp) instead of
-        // v_sqrt_f32 + v_rcp_f32 + a Newton step - two quarter-rate instructions fewer per layer and wave type
-        float ra, ira = 0.0f;
-        if constexpr (FACT) {
-            const float xa = fabsf(arga), ya = __builtin_amdgcn_rsqf(xa);
-            ra = (xa > 0.0f) ? xa * ya : 0.0f;
-            ira = ya;
-            if (arga > 0.0f) { ra = -ra; ira = -ira; }
-        } else {
-            ra = sqrt_hw(fabsf(arga));
-            if (arga > 0.0f) ra = -ra;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const float sv = y.sv, d = y.d, ia2 = y.ia2, ib2 = y.ib2;
+        if (!FIRST) {                                      // into this layer's scale: rhoc_prev / rhoc = rho_prev / rho
+            const float rat = rho_prev * y.ir;
+            h2 *= rat; h3 *= rat; h4 *= rat; h5 *= rat * rat;
         }
+        rho_prev = y.rho;
+        const float arga = fmaf(-csq, ia2, 1.0f);                    // 1 - c^2/a^2, surfa.f:211
+        const float xa = fabsf(arga), ya = __builtin_amdgcn_rsqf(xa);
+        float ra = (xa > 0.0f) ? xa * ya : 0.0f, ira = ya;           // ra = x rsq(x) to ~1.5 ulp
+        if (arga > 0.0f) { ra = -ra; ira = -ira; }
         const float wd = wvno * d;
-        const float rhoc = rho * csq;
-        if (MAYBE_LIQUID && !(fabsf(sv) > ACCUR)) {
-            // liquid surface layer, surfa.f:216-251 (skipped entirely in the ellipticity passes)
+        if (FIRST && !(fabsf(sv) > ACCUR)) {
+            // liquid surface layer, surfa.f:216-251 (skipped entirely in the ellipticity passes): only a11 = cosp and
+            // a21 = rhoc sinpr are non-zero (surfa.f:236-250)
             if (start != 1) return;
             const float pm = wd * ra;
             float sinpr, cosp;
             if (fabsf(ra) < ACCUR) { sinpr = wd; cosp = 1.0f; }
             else if (ra < 0.0f) {
-                float sh, ch;
-                if constexpr (FACT) sinhcosh_sp(pm, &sh, &ch); else sinhcosh_ref(pm, &sh, &ch);
+                float sh, ch; sinhcosh_sp(pm, &sh, &ch);
                 sinpr = sh / ra;
                 cosp = ch;
             } else {
@@ -382,69 +388,41 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
                 sinpr = sn / ra; cosp = cs;
                 phi += pm;
             }
-            // only a11 and a21 are non-zero (surfa.f:236-250)
             const float n1 = cosp * b1;
-            const float n2 = rhoc * sinpr * b1;
-            const float n5 = cosp * b5 - rhoc * sinpr * b4;
-            b1 = n1; b2 = n2; b3 = 0.0f; b4 = 0.0f; b5 = n5;
+            const float n2 = sinpr * b1;
+            const float n5 = cosp * h5 - sinpr * h4;
+            b1 = n1; h2 = n2; h3 = 0.0f; h4 = 0.0f; h5 = n5;
             return;
         }
         const float argb = fmaf(-csq, ib2, 1.0f);
-        float rb, irb = 0.0f;
-        if constexpr (FACT) {
-            const float xb = fabsf(argb), yb = __builtin_amdgcn_rsqf(xb);
-            rb = (xb > 0.0f) ? xb * yb : 0.0f;
-            irb = yb;
-            if (argb > 0.0f) { rb = -rb; irb = -irb; }
-        } else {
-            rb = sqrt_hw(fabsf(argb));
-            if (argb > 0.0f) rb = -rb;
-        }
+        const float xb = fabsf(argb), yb = __builtin_amdgcn_rsqf(xb);
+        float rb = (xb > 0.0f) ? xb * yb : 0.0f, irb = yb;
+        if (argb > 0.0f) { rb = -rb; irb = -irb; }
         const float g = 2.0f * (sv * sv) * icsq;
         const float g1 = g - 1.0f;
-        const float irhoc = irho * icsq;
         const float pm = wd * ra;
         const float qm = wd * rb;
         float rsinp, sinpr, cosp, rsinq, sinqr, cosq;
         if (ra < 0.0f) {                                   // evanescent P, surfa.f:267-269
-            float sh, ch;
-            if constexpr (FACT) sinhcosh_sp(pm, &sh, &ch); else sinhcosh_ref(pm, &sh, &ch);
-            rsinp = -ra * sh;
-            sinpr = sh * (FACT ? ira : rcp_nr(ra));
-            cosp = ch;
+            float sh, ch; sinhcosh_sp(pm, &sh, &ch);
+            rsinp = -ra * sh; sinpr = sh * ira; cosp = ch;
         } else if (ra == 0.0f) {
             rsinp = 0.0f; sinpr = wd; cosp = 1.0f;
         } else {                                           // oscillatory P, surfa.f:271-273
             float sn, cs; sincos_cw(pm, &sn, &cs);
-            rsinp = ra * sn; sinpr = sn * (FACT ? ira : rcp_nr(ra)); cosp = cs;
+            rsinp = ra * sn; sinpr = sn * ira; cosp = cs;
             phi += pm;
         }
         if (fabsf(rb) < ACCUR) {
             rsinq = 0.0f; sinqr = wd; cosq = 1.0f;
         } else if (rb > 0.0f) {
             float sn, cs; sincos_cw(qm, &sn, &cs);
-            rsinq = rb * sn; sinqr = sn * (FACT ? irb : rcp_nr(rb)); cosq = cs;
+            rsinq = rb * sn; sinqr = sn * irb; cosq = cs;
             phi += qm;
         } else {
-            float sh, ch;
-            if constexpr (FACT) sinhcosh_sp(qm, &sh, &ch); else sinhcosh_ref(qm, &sh, &ch);
-            rsinq = -rb * sh;
-            sinqr = sh * (FACT ? irb : rcp_nr(rb));
-            cosq = ch;
+            float sh, ch; sinhcosh_sp(qm, &sh, &ch);
+            rsinq = -rb * sh; sinqr = sh * irb; cosq = ch;
         }
-        float n1, n2, n3, n4, n5;
-        if constexpr (FACT) {
-        // Factorised application of the layer's compound matrix.  Its fifteen entries (surfa.f:289-320) are linear
-        // in the nine products (cosp, rsinp, sinpr) x (cosq, rsinq, sinqr); collecting the update by product
-        // instead of by matrix entry gives, exactly (algebraic identity, checked in fp64 to 3e-14),
-        //   h = (b2, b3, b4)/rhoc, h5 = b5/rhoc^2,  u1 = g^2 b1 + 2g h3 - h5,  u2 = g1^2 b1 + 2g1 h3 - h5,
-        //   E1 = rsinp (rsinq u1 + cosq h2) - cosp rsinq h4 + (1 - cosp cosq) u2,
-        //   E2 = sinpr (sinqr u2 - cosq h4) + cosp sinqr h2 + (1 - cosp cosq) u1,
-        //   b1' = b1 - E1 - E2,  b3' = rhoc (h3 + g E1 + g1 E2),  b5' = rhoc^2 (h5 + g^2 E1 + g1^2 E2),
-        //   b2' = rhoc (cosp (cosq h2 + rsinq u1) + sinpr (rsinq h4 + cosq u2)),
-        //   b4' = rhoc (rsinp (sinqr h2 - cosq u1) - cosp (sinqr u2 - cosq h4))
-        // in 46 instead of ~100 operations, with the same fp32 accuracy against an fp64 evaluation.
-        const float h2 = b2 * irhoc, h3 = b3 * irhoc, h4 = b4 * irhoc, h5 = (b5 * irhoc) * irhoc;
         const float g2 = g * g, g12 = g1 * g1;
         const float u1 = fmaf(g2, b1, fmaf(g + g, h3, -h5));
         const float u2 = fmaf(g12, b1, fmaf(g1 + g1, h3, -h5));
@@ -454,49 +432,12 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         const float Cx = cosp * rsinq, Cy = cosp * sinqr;
         const float E1 = fmaf(rsinp, t1, fmaf(-Cx, h4, D * u2));
         const float E2 = fmaf(sinpr, t2, fmaf(Cy, h2, D * u1));
-        n1 = (b1 - E1) - E2;
-        n3 = rhoc * fmaf(g, E1, fmaf(g1, E2, h3));
-        n5 = (rhoc * rhoc) * fmaf(g2, E1, fmaf(g12, E2, h5));
-        n2 = rhoc * fmaf(cosp, t1, sinpr * fmaf(rsinq, h4, cosq * u2));
-        n4 = rhoc * fmaf(rsinp, fmaf(sinqr, h2, -(cosq * u1)), -(cosp * t2));
-        } else {
-        // the fifteen distinct entries, surfa.f:289-320 (common factors g*rr, g1*ss and their multiples
-        // computed once)
-        const float rr = rsinp * rsinq, ss = sinpr * sinqr, cc = cosp * cosq;
-        const float rs1 = rsinp * cosq, rs2 = sinqr * cosp, rs3 = sinpr * cosq, rs4 = rsinq * cosp;
-        const float gm = 2.0f * g - 1.0f;
-        const float gs = g * g, g1s = g1 * g1;
-        const float ccm = 1.0f - cc;
-        const float gg1 = g * g1;
-        const float rhocs = rhoc * rhoc;
-        const float X = g * rr, Y = g1 * ss;                   // g rr, g1 ss
-        const float gX = g * X, g1Y = g1 * Y;                  // g^2 rr, g1^2 ss
-        const float Z = g * gX, W = g1 * g1Y;                  // g^3 rr, g1^3 ss
-        const float gg1c = gg1 * ccm;
-        const float suu = gX + g1Y;
-        const float a11 = (2.0f * gs - gm) * cc - suu - 2.0f * gg1;
-        const float a12 = -(rs1 + rs2) * irhoc;
-        const float a13 = -2.0f * (gm * ccm + Y + X) * irhoc;
-        const float a14 = (rs3 + rs4) * irhoc;
-        const float a15 = (2.0f * ccm + rr + ss) * (irhoc * irhoc);
-        const float a21 = rhoc * (g1s * rs3 + gs * rs4);
-        const float a22 = cc;
-        const float a23 = 2.0f * (g * rs4 + g1 * rs3);
-        const float a24 = sinpr * rsinq;
-        const float a31 = rhoc * (gm * gg1c + W + Z);
-        const float a32 = g1 * rs2 + g * rs1;
-        const float a33 = 1.0f + 2.0f * (2.0f * gg1c + suu);
-        const float a41 = -rhoc * (g1s * rs2 + gs * rs1);
-        const float a42 = rsinp * sinqr;
-        const float a51 = rhocs * (2.0f * gg1 * gg1c + g * Z + g1 * W);
-        // compound-matrix product with its symmetries, surfa.f:326-330
-        n1 = a11 * b1 + a12 * b2 + a13 * b3 + a14 * b4 + a15 * b5;
-        n2 = a21 * b1 + a22 * b2 + a23 * b3 + a24 * b4 - a14 * b5;
-        n3 = a31 * b1 + a32 * b2 + a33 * b3 - 0.5f * a23 * b4 + 0.5f * a13 * b5;
-        n4 = a41 * b1 + a42 * b2 - 2.0f * a32 * b3 + a22 * b4 - a12 * b5;
-        n5 = a51 * b1 - a41 * b2 + 2.0f * a31 * b3 - a21 * b4 + a11 * b5;
-        }
-        b1 = n1; b2 = n2; b3 = n3; b4 = n4; b5 = n5;
+        const float n1 = (b1 - E1) - E2;
+        const float n3 = fmaf(g, E1, fmaf(g1, E2, h3));
+        const float n5 = fmaf(g2, E1, fmaf(g12, E2, h5));
+        const float n2 = fmaf(cosp, t1, sinpr * fmaf(rsinq, h4, cosq * u2));
+        const float n4 = fmaf(rsinp, fmaf(sinqr, h2, -(cosq * u1)), -(cosp * t2));
+        b1 = n1; h2 = n2; h3 = n3; h4 = n4; h5 = n5;
     };
     const int last = mmax - 1;                                       // the half space
     Lyr A = load(0);
@@ -519,14 +460,14 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         step(A, std::false_type{});
         A = Bq;
     }
-    const float n_sv = A.sv, n_ir = A.ir, n_ia2 = A.ia2, n_ib2 = A.ib2;   // layer mmax-1
-    // half-space closure, surfa.f:340-354
+    // half-space closure, surfa.f:340-354, on (b1, rhoc h2..h4, rhoc^2 h5) with rhoc of the last layer gone through
     // (a itself is not needed: every occurrence is a^2, available as 1/ia2)
-    const float sv = n_sv, irho = n_ir, ia2 = n_ia2;                 // n_* hold layer mmax-1 here
+    const float sv = A.sv, irho = A.ir, ia2 = A.ia2;                 // A holds layer mmax-1 here
+    const float rhoc = rho_prev * csq;
     const float arga = fmaf(-csq, ia2, 1.0f);
     float ra = sqrt_hw(fabsf(arga));
     if (arga > 0.0f) ra = -ra;
-    const float argb = fmaf(-csq, n_ib2, 1.0f);
+    const float argb = fmaf(-csq, A.ib2, 1.0f);
     float rb = sqrt_hw(fabsf(argb));
     if (argb > 0.0f) rb = -rb;
     const float sss = sv * sv;
@@ -541,7 +482,7 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
     const float h14 = rb * it12 * igra;
     const float h15 = rba * (irho * irho) * ia2 * icsq * ig;         // rba/(rho a)^2/c^2/g
     const float h12 = -ig * it12;
-    const float bb1 = h11 * b1 + h12 * b2 + 2.0f * h13 * b3 + h14 * b4 + h15 * b5;
+    const float bb1 = h11 * b1 + rhoc * (h12 * h2 + 2.0f * h13 * h3 + h14 * h4 + rhoc * (h15 * h5));
     return (start == 1) ? -bb1 : bb1;
 }
 
@@ -989,7 +930,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         float val = 0.0f, phj = 0.0f;
         if (eval) {
             if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, Lcap, S, mmj, cj, Tl, start)
-                                       : delta_rayleigh<true>(wl, Lcap, S, mmj, cj, Tl, start, phj);
+                                       : delta_rayleigh(wl, Lcap, S, mmj, cj, Tl, start, phj);
             else           val = EXACT ? delta_love_ref(wl, Lcap, S, mmj, cj, Tl) : delta_love<false>(wl, Lcap, S, mmj, cj, Tl, phj);
         }
         // ---------------------------------------------------------------- team-level decisions

@@ -1,5 +1,5 @@
 // scripts/microbench/issue_rate.hip -- development microbenchmark: what VALU issue rate does the
-// Rayleigh layer recursion (delta_rayleigh<true> of surfdisp_kernels.hip, the production form, unchanged) sustain on gfx950 when
+// Rayleigh layer recursion (delta_rayleigh of surfdisp_kernels.hip, the production form, unchanged) sustain on gfx950 when
 // nothing else is in the way -- no state machine, no root search, every wavefront busy for the whole
 // launch?  Modes: 0 = every lane the same trial velocity (no divergence), 1 = lanes spread over
 // 3.0..4.4 km/s like the teams of the real kernel (evanescent / oscillatory S mixes inside a wave),
@@ -34,15 +34,15 @@ __global__ __launch_bounds__(256) void issue_kernel(float *out, int iters, int L
         // two independent evaluations per lane and iteration (instruction-level parallelism 2)
         float c2 = c + 0.005f;
         for (int it = 0; it < iters / 2; ++it) {
-            const float v = delta_rayleigh<true>(wq, Lcap, S, L, c, T, 1, phi_);
-            const float w = delta_rayleigh<true>(wq, Lcap, S, L, c2, T, 1, phi_);
+            const float v = delta_rayleigh(wq, Lcap, S, L, c, T, 1, phi_);
+            const float w = delta_rayleigh(wq, Lcap, S, L, c2, T, 1, phi_);
             acc += v + w;
             c += (v > 1e30f) ? 1e-3f : 0.0f;
             c2 += (w > 1e30f) ? 1e-3f : 0.0f;
         }
     } else {
         for (int it = 0; it < iters; ++it) {
-            const float v = delta_rayleigh<true>(wq, Lcap, S, L, c, T, 1, phi_);
+            const float v = delta_rayleigh(wq, Lcap, S, L, c, T, 1, phi_);
             acc += v;
             c += (v > 1e30f) ? 1e-3f : 0.0f;                  // keeps the loop from being hoisted
         }
