@@ -368,9 +368,11 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         }
         rho_prev = y.rho;
         const float arga = fmaf(-csq, ia2, 1.0f);                    // 1 - c^2/a^2, surfa.f:211
-        const float xa = fabsf(arga), ya = __builtin_amdgcn_rsqf(xa);
-        float ra = (xa > 0.0f) ? xa * ya : 0.0f, ira = ya;           // ra = x rsq(x) to ~1.5 ulp
-        if (arga > 0.0f) { ra = -ra; ira = -ira; }
+        // |arga| is clamped away from zero: c == a to the last bit then runs through the oscillatory formulas with
+        // ra = 1e-15, which give the reference's degenerate values (rsinp = 0, sinpr = k d, cosp = 1; surfa.f:263-266)
+        // to 1e-15 - no separate branch
+        const float xa = fmaxf(fabsf(arga), 1.0e-30f), ya = __builtin_amdgcn_rsqf(xa);
+        const float ra = copysignf(xa * ya, -arga), ira = copysignf(ya, -arga);   // ra = x rsq(x) to ~1.5 ulp; < 0: evanescent
         const float wd = wvno * d;
         if (FIRST && !(fabsf(sv) > ACCUR)) {
             // liquid surface layer, surfa.f:216-251 (skipped entirely in the ellipticity passes): only a11 = cosp and
@@ -395,27 +397,22 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             return;
         }
         const float argb = fmaf(-csq, ib2, 1.0f);
-        const float xb = fabsf(argb), yb = __builtin_amdgcn_rsqf(xb);
-        float rb = (xb > 0.0f) ? xb * yb : 0.0f, irb = yb;
-        if (argb > 0.0f) { rb = -rb; irb = -irb; }
+        const float xb = fmaxf(fabsf(argb), 1.0e-30f), yb = __builtin_amdgcn_rsqf(xb);    // same for c == b (surfa.f:275-279)
+        const float rb = copysignf(xb * yb, -argb), irb = copysignf(yb, -argb);
         const float g = 2.0f * (sv * sv) * icsq;
         const float g1 = g - 1.0f;
         const float pm = wd * ra;
         const float qm = wd * rb;
         float rsinp, sinpr, cosp, rsinq, sinqr, cosq;
-        if (ra < 0.0f) {                                   // evanescent P, surfa.f:267-269
+        if (arga > 0.0f) {                                 // evanescent P (ra < 0), surfa.f:267-269
             float sh, ch; sinhcosh_sp(pm, &sh, &ch);
             rsinp = -ra * sh; sinpr = sh * ira; cosp = ch;
-        } else if (ra == 0.0f) {
-            rsinp = 0.0f; sinpr = wd; cosp = 1.0f;
         } else {                                           // oscillatory P, surfa.f:271-273
             float sn, cs; sincos_cw(pm, &sn, &cs);
             rsinp = ra * sn; sinpr = sn * ira; cosp = cs;
             phi += pm;
         }
-        if (fabsf(rb) < ACCUR) {
-            rsinq = 0.0f; sinqr = wd; cosq = 1.0f;
-        } else if (rb > 0.0f) {
+        if (!(argb > 0.0f)) {
             float sn, cs; sincos_cw(qm, &sn, &cs);
             rsinq = rb * sn; sinqr = sn * irb; cosq = cs;
             phi += qm;
