@@ -281,7 +281,7 @@ __device__ __forceinline__ void sinhcosh_sp(float x, float *sh, float *ch)
 {
     // no low-order correction of x log2(e): e^x and e^-x then carry relative errors +-|x| 9e-8, which for |x| > 1 is a
     // common scale factor of sinh and cosh (the secular function's root does not move) and for |x| < 1 is below one
-    // ulp anyway - golden-case parity unchanged, root search 6 % faster (profiles/r02c/ab_exp_rcp.txt)
+    // ulp anyway - golden-case parity unchanged, root search 6 % faster (profiles/r02d/ab_recursion_variants.txt)
     const float t = x * 1.44269502e+00f;
     const float p = __builtin_amdgcn_exp2f(t - 1.0f), q = __builtin_amdgcn_exp2f(-t - 1.0f);
     *sh = p - q;
