@@ -15,7 +15,7 @@ MONO = os.environ.get("SOAK_MONO", "1") == "1"
 ONLY = os.environ.get("SOAK_ONLY")                      # 'wild' / 'sediment': that family only (sediment: wider ranges)
 VSMIN = float(os.environ.get("SOAK_WILD_VSMIN", "0.1"))
 T_LAST = time.time()
-nst = nval = ndif = npat = ncase = 0
+nst = nval = ndif = npat = ncase = nbig = 0
 byfam = {}
 # realistic stacks: uniform prior draws of the continental and the thermal oceanic parametrisation (tests/golden)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -80,6 +80,9 @@ while time.time() < T_END:
     c1, u1, s1 = plan.run(md, pd, kind=kind | 0x10, fast_scan=True, **kw)                          # opt-in SURFDISP_FASTSCAN
     d = (c0 != c1)
     nd = int(d.sum()); ndif += nd; nval += c0.numel(); nst += B; ncase += 1
+    # another ROOT (not the last bits: a stack the two scans hand to different kernels - production / exact fallback -
+    # differs at the 1e-7 level)
+    nbig += int(((c0 - c1).abs() > 1e-5 * c0.abs().clamp(min=1e-3)).sum())
     npat += int(((c0 > 0) != (c1 > 0)).any(dim=1).sum())
     f = byfam.setdefault((fam, kind), [0, 0, 0]); f[0] += c0.numel(); f[1] += nd; f[2] += int(((c0 > 0) != (c1 > 0)).sum())
     if nd:
@@ -96,7 +99,7 @@ if saved:
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     np.save(os.path.join(ROOT, 'gpurun_out', 'scanfail.npy'), np.array(saved, dtype=object), allow_pickle=True)
 print(f"scan soak, fast vs default scan (monotone only: {MONO}): {ncase} cases, {nst} stacks, {nval} phase velocities; {ndif} differ ({ndif / max(nval, 1):.2e}); "
-      f"{npat} stacks with a different zero pattern")
+      f"{nbig} of them by more than 1e-5 relative (another root); {npat} stacks with a different zero pattern")
 for k, v in sorted(byfam.items()):
     print(f"   family {k[0]:9s} kind {k[1]}: {v[0]} values, {v[1]} differ, {v[2]} of them zero/non-zero")
 for w in sorted(worst, reverse=True)[:15]:
