@@ -32,10 +32,10 @@ struct PhaseArgs {
     int *status;          // [B] or nullptr
     float wtol;           // bracket width below which the root may be read off by interpolation
     float atol;           // ... provided secant and 3-point estimates agree to this (km/s)
-    int fast;             // certified coarse-to-fine scan (the default; 0 with SURFDISP_EXACTSCAN)
+    int fast;             // opt-in heuristic coarse-to-fine scan (SURFDISP_FASTSCAN); 0 = every grid point, the default
     const float *fsafe;   // [B], see PrepArgs
     int overlap;          // second LDS slot: the ellipticity passes ride in the next period's first scan pass
-    float phimax;         // certified scan: largest vertical-phase increment (rad) of an interval that may be skipped
+    float phimax;         // fast scan: largest vertical-phase increment (rad) of an interval that may be skipped
     const float *ovf;     // [3][B], see PrepArgs
     int *fb_count;        // [1] number of entries of fb_list
     int *fb_list;         // [teams]: team indices (stack, or period * B + stack in independent mode) for the exact kernel

@@ -18,9 +18,11 @@
 //                               recursion state in registers.  Periods are walked in order inside the
 //                               team (faithful start rule c1 = 0.9*c(k-1), mmax carry-over, failure
 //                               guards, NaN semantics: calcul.f:104-220).  Template flags: INDEP (one
-//                               team per (stack, period), SURFDISP_INDEPENDENT), FAST (certified
-//                               coarse-to-fine scan; off with SURFDISP_EXACTSCAN); phase-only calls skip the
-//                               ellipticity recursions.
+//                               team per (stack, period), SURFDISP_INDEPENDENT), FAST (opt-in heuristic
+//                               scan, SURFDISP_FASTSCAN), EXACT (the fallback instantiation that restates
+//                               DLTAR4 / DLTAR1 / NEVILL statement by statement for the stacks the
+//                               production arithmetic cannot treat faithfully); phase-only calls skip
+//                               the ellipticity recursions.
 //   K2 surfdisp_group_kernel  : group velocities, one lane per (stack, period): eigenfunction
 //                               integration + energy integrals (surfa.f:714-1192 / 374-606), fp64 state
 //                               for Rayleigh as in the reference (surfa.f:717-722); the KERN
@@ -761,9 +763,9 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
     bool p0ok = false;                 // p0d was computed with mm_frozen (usable for interpolation)
     bool first = true;
     int status = SURFDISP_OK;
-    // certified coarse-to-fine scan (teams of 2..8 lanes): after the first pass of a period the scan advances
+    // opt-in fast scan (teams of 2..8 lanes): after the first pass of a period the scan advances
     // FSTRIDE grid points per lane; an interval between two coarse points is skipped only if it is
-    // certified free of sign changes (see below), otherwise its fine points are scanned as usual
+    // judged free of sign changes (see below), otherwise its fine points are scanned as usual
     constexpr int FSTRIDE = 4;
     constexpr bool fastok = FAST && (G >= 2) && (G <= 8);
     // ... and only on stacks where two modes cannot sit within one coarse interval: velocities that never
@@ -1979,7 +1981,7 @@ hipError_t launch_phase_x(hipStream_t s, const sd::PhaseArgs &a)
 template <int KIND, bool INDEP>
 hipError_t launch_phase_k(hipStream_t s, const sd::PhaseArgs &a, int G)
 {
-    if (a.fast) {                                  // certified coarse-to-fine scan: teams of 2..8 lanes only
+    if (a.fast) {                                  // opt-in fast scan: teams of 2..8 lanes only
         switch (G) {
             case 2:  return launch_phase_g<KIND, 2, INDEP, true>(s, a);
             case 4:  return launch_phase_g<KIND, 4, INDEP, true>(s, a);

@@ -37,7 +37,7 @@ def sediment_models(B: int, L: int, seed: int = 0, noise: float = 0.05, total_th
     """Soft sediments (Vs 0.2-1.4 km/s, Vp/Vs 1.8-3.5, one to four layers of 0.2-3 km) over the monotone rock
     stack of ``synth_models``: fundamental and first higher Rayleigh mode come within 0.02 km/s of each other
     and the secular function carries e^{kd} factors of many orders of magnitude -- the hard case for the
-    certified scan (tests/test_gpu_parity.py, scripts/soak_scan.py)."""
+    opt-in fast scan (tests/test_gpu_parity.py, scripts/soak_scan.py)."""
     rng = np.random.default_rng(seed)
     m = synth_models(B, L, seed=seed + 1, noise=noise, monotone=True, total_thickness=total_thickness)
     ns = int(rng.integers(1, min(max_layers, L - 1) + 1))

@@ -82,7 +82,7 @@ def test_synth_generator_is_deterministic_and_shaped():
 
 
 def test_sediment_family_is_monotone_and_deterministic():
-    """synth.sediment_models feeds the certified-scan GPU test and the scan soak: Vs and Vp never decrease with
+    """synth.sediment_models feeds the fast-scan GPU test and the scan soak: Vs and Vp never decrease with
     depth (otherwise the root search scans exactly and the test proves nothing), same seed -> same stacks."""
     from pysurfinv_amd import synth
     for kw in ({}, dict(max_layers=12), dict(water=True), dict(max_layers=12, water=True)):
