@@ -248,12 +248,16 @@ def workload_forward(rt, args):
             roof.update({"achieved": v["valu_wave_instructions"] / phase_s,
                          "frac": v["valu_wave_instructions"] / phase_s / VALU_PEAK,
                          "traffic": tj.get("phase_kernel_hbm_bytes_per_launch"),
+                         "frac_measured_issue_costs": (v["valu_issue_frac_measured_costs"] * (v["kernel_cycles"] / CLOCK_HZ) / phase_s
+                                                       if "valu_issue_frac_measured_costs" in v else None),
                          "valu_pmc": v, "pmc_profile": tj.get("round"), "pmc_lib_sha256_16": tj.get("lib_sha256_16"),
                          "this_lib_sha256_16": here, "pmc_matches_this_build": bool(same),
                          "note": "achieved = wave-level VALU instructions per launch (SQ_INSTS_VALU of the committed "
                                  "rocprofv3 --pmc pass named in pmc_profile) / the LIVE duration of the kernel (HIP "
-                                 "events on its stream); peak = 1024 SIMDs x 2.4 GHz / 2 cycles per instruction (quarter-"
-                                 "rate transcendentals are 8 % of the stream, so the pipe is busier than frac says); "
+                                 "events on its stream); peak = 1024 SIMDs x 2.4 GHz / 2 cycles per instruction; "
+                                 "frac_measured_issue_costs prices the same stream with the costs measured on this chip "
+                                 "(scripts/microbench/valu_rates.hip: plain fp32 2.2, transcendental 8.1, fp64 4.2 SIMD "
+                                 "cycles per wave instruction) - the share of the SIMDs' issue time the kernel fills; "
                                  "traffic = HBM bytes per launch from the same passes (FETCH_SIZE x 2 + WRITE_SIZE)"
                                  + ("" if same else "; WARNING: the profile was taken with another build of the library")})
         except Exception as e:                                   # a broken profile file must not kill the line

@@ -61,6 +61,12 @@ extern "C" {
                                      * different roots or a different zero pattern.  Callers who need the reference's
                                      * root selection on every input leave it off.  Also switched on for every call of
                                      * the process by the environment variable SURFDISP_FASTSCAN=1 (read once). */
+#define SURFDISP_STRICT        0x200 /* OR into `kind`: verification mode.  EVERY stack is solved by the kernel that restates
+                                     * DLTAR4 / DLTAR1 / NEVILL statement by statement (the one the default mode keeps for
+                                     * stacks whose secular function leaves the fp32 range): the reference's own matrix-entry
+                                     * arithmetic, overflow points and evaluation sequence, several times slower.  The default
+                                     * mode agrees with it to ~1e-6 on c; use it to check that on your own models
+                                     * (tests/test_gpu_parity.py does, at the bench size), not in production. */
 #define SURFDISP_PHASE_ONLY    0x10 /* OR into `kind` of the batched entries: phase velocities only
                                      * (what Point.misfit consumes, point.py:18); u is not written
                                      * and may be NULL */

@@ -20,6 +20,7 @@ INDEPENDENT = 0x20
 PIPELINED = 0x40
 EXACTSCAN = 0x80        # ABI 1 spelling, accepted and ignored: the point-by-point scan is the default
 FASTSCAN = 0x100        # opt-in heuristic scan (include/surfdisp.h)
+STRICT = 0x200          # verification mode: every stack through the statement-by-statement kernel
 NPER_MAX, NLAY_MAX = 200, 200
 
 # every symbol include/surfdisp.h declares

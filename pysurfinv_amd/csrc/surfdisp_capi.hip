@@ -55,7 +55,7 @@ void set_err(const char *fmt, const char *a = "", const char *b = "")
     } while (0)
 
 constexpr int SD_KIND_FLAGS = SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED | SURFDISP_EXACTSCAN |
-                             SURFDISP_FASTSCAN;
+                             SURFDISP_FASTSCAN | SURFDISP_STRICT;
 
 size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -213,7 +213,8 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     // the reference's point-by-point scan unless the caller (flag) or the process (environment) opted into the
     // heuristic one; SURFDISP_EXACTSCAN (ABI 1) is accepted and wins over both
     const EnvKnobs &kn = knobs();
-    const bool fastscan = ((kind & SURFDISP_FASTSCAN) != 0 || kn.fastscan) && (kind & SURFDISP_EXACTSCAN) == 0;
+    const bool strict = (kind & SURFDISP_STRICT) != 0;
+    const bool fastscan = ((kind & SURFDISP_FASTSCAN) != 0 || kn.fastscan) && (kind & SURFDISP_EXACTSCAN) == 0 && !strict;
     kind &= ~SD_KIND_FLAGS;
     const Carve w = carve(workspace, B, Lmax, P);
     // independent mode has B*P root searches in flight: size the teams for that many; a caller that
@@ -228,7 +229,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     const float wtol = kn.refine_wtol, atol = kn.refine_atol, phimax = kn.phimax;
     sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, phase_only ? nullptr : w.ratio, w.nsolved, status, wtol, atol,
                      fastscan ? 1 : 0, w.fsafe, (!phase_only && use_overlap(Lmax, G)) ? 1 : 0, phimax,
-                     w.ovf, w.fb_count, w.fb_list, kn.balance >= 0 ? kn.balance : (pipelined ? 0 : 1)};
+                     w.ovf, w.fb_count, w.fb_list, kn.balance >= 0 ? kn.balance : (pipelined ? 0 : 1), strict ? 1 : 0};
 #ifdef SD_WAVECLOCK
     ph.wclk = reinterpret_cast<unsigned long long *>(g_dbg.load(std::memory_order_relaxed));
 #endif

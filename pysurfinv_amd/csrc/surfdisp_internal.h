@@ -40,6 +40,7 @@ struct PhaseArgs {
     int *fb_count;        // [1] number of entries of fb_list
     int *fb_list;         // [teams]: team indices (stack, or period * B + stack in independent mode) for the exact kernel
     int balance;          // wavefront priority by progress (one batch in flight), see the kernel's main loop
+    int strict;           // SURFDISP_STRICT: every team hands its stack to the exact kernel
 #ifdef SD_WAVECLOCK
     unsigned long long *wclk;   // developer build: [waves][2] s_memrealtime at wavefront start / end
 #endif

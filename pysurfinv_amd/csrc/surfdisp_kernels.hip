@@ -856,7 +856,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         p0c = qq * (1.0f + b_corr);
         if (water) p0c = 0.5f;
         first = true;
-        defer = entry_overflow_risk(p0c);
+        defer = (!EXACT && A.strict != 0) || entry_overflow_risk(p0c);    // SURFDISP_STRICT: everything to the exact kernel
         nodrop = no_drop_possible(p0c);
     }
 

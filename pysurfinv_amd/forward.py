@@ -41,15 +41,18 @@ def _calForward(inProfile, wavetype="Ray", periods=(5, 10, 20, 40, 60, 80), debu
     return cr0[:nper]
 
 
-def forward_batch(model, periods, kind=2, nlay=None, device=0, independent=False, fast_scan=False):
+def forward_batch(model, periods, kind=2, nlay=None, device=0, independent=False, fast_scan=False, strict=False):
     """model float32 [B,5,L] rows (vp, vs, rho, h, qsinv) -> (c[B,P], u[B,P], status[B]).
 
     Host buffers in, host buffers out (C ABI surfdisp_forward_batch).  ``independent=True`` ORs
     SURFDISP_INDEPENDENT into ``kind`` (one team per (stack, period); see include/surfdisp.h).
     The scan evaluates every 0.01 km/s grid point as the reference does; ``fast_scan=True`` opts into the
-    heuristic coarse-to-fine scan (SURFDISP_FASTSCAN)."""
+    heuristic coarse-to-fine scan (SURFDISP_FASTSCAN); ``strict=True`` solves every stack with the kernel that restates
+    the reference's arithmetic statement by statement (SURFDISP_STRICT: a verification mode, several times slower)."""
     if independent:
         kind = int(kind) | _lib.INDEPENDENT
+    if strict:
+        kind = int(kind) | _lib.STRICT
     if fast_scan:                                  # opt-in heuristic scan (SURFDISP_FASTSCAN); default: every grid point
         kind = int(kind) | _lib.FASTSCAN
     L = _lib.lib()
@@ -101,7 +104,7 @@ class BatchPlan:
         return self.run(model, periods, kind=kind, nlay=nlay, _timed=True, independent=independent)
 
     def run(self, model, periods, kind=2, nlay=None, _timed=False, independent=False, events=None,
-            pipelined=False, fast_scan=False):
+            pipelined=False, fast_scan=False, strict=False):
         """Launch the kernels on torch's current stream (no allocation, no sync).  ``events``: an
         ``EventRing`` slot (4 HIP events recorded on the launch stream around the kernels).
         ``pipelined``: the caller keeps a second batch in flight on another stream
@@ -113,6 +116,8 @@ class BatchPlan:
             kind = int(kind) | _lib.PIPELINED
         if fast_scan:                                  # opt-in heuristic scan (SURFDISP_FASTSCAN)
             kind = int(kind) | _lib.FASTSCAN
+        if strict:                                     # verification mode (SURFDISP_STRICT): the exact kernel for every stack
+            kind = int(kind) | _lib.STRICT
         for t, shape in ((model, (self.B, 5, self.L)), (periods, (self.P,))):
             if (t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shape
                     or t.device != self.device):

@@ -35,6 +35,9 @@ def short(name):
     return None
 
 
+COST_PLAIN, COST_TRANS, COST_F64 = 2.2, 8.1, 4.2      # SIMD cycles per wave-level instruction, measured
+
+
 def main(tag):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles", tag)
@@ -78,6 +81,15 @@ def main(tag):
                 "wave_wait_inst_frac": mean[(k, "SQ_WAIT_INST_ANY")] / wc,
                 "wave_wait_any_frac": mean[(k, "SQ_WAIT_ANY")] / wc,
             }
+            # the same share priced with the issue costs measured on this chip (scripts/microbench/valu_rates.hip,
+            # profiles/r02e/valu_rates.txt, 4 wavefronts per SIMD): plain fp32 2.2 cycles, transcendental 8.1, fp64 4.2
+            tr32 = mean.get((k, "SQ_INSTS_VALU_TRANS_F32"))
+            if tr32 is not None:
+                f64 = sum(mean.get((k, "SQ_INSTS_VALU_%s_F64" % t), 0.0) for t in ("ADD", "MUL", "FMA"))
+                tr64 = mean.get((k, "SQ_INSTS_VALU_TRANS_F64"), 0.0)
+                plain = mean[(k, "SQ_INSTS_VALU")] - tr32 - f64 - tr64
+                valu[k]["valu_issue_frac_measured_costs"] = (plain * COST_PLAIN + (tr32 + tr64) * COST_TRANS + f64 * COST_F64) / (SIMDS * cyc)
+                valu[k]["instruction_classes"] = {"plain": plain, "transcendental": tr32 + tr64, "fp64": f64}
     import hashlib
     with open(os.path.join(ROOT, "pysurfinv_amd", "lib", "libsurfdisp_hip.so"), "rb") as fh:
         lib_hash = hashlib.sha256(fh.read()).hexdigest()[:16]
@@ -91,7 +103,8 @@ def main(tag):
         "method": "rocprofv3 --pmc in separate passes (scripts/profile.sh, scripts/summarise_profile.py); "
                   "FETCH_SIZE/WRITE_SIZE KB->bytes x1024; FETCH_SIZE x2 (gfx950 correction, calibrated on the prep "
                   "kernel's 13.1 MB model read); VALU issue share = SQ_INSTS_VALU*2 cycles / (1024 SIMDs * "
-                  "GRBM_GUI_ACTIVE/8)",
+                  "GRBM_GUI_ACTIVE/8); valu_issue_frac_measured_costs prices plain / transcendental / fp64 instructions "
+                  "at 2.2 / 8.1 / 4.2 SIMD cycles (scripts/microbench/valu_rates.hip)",
     }
     with open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w") as fh:
         json.dump(out, fh, indent=1)
