@@ -258,7 +258,7 @@ SD_HD __forceinline__ LayerV layer_at(const float *__restrict__ mdl, size_t fs, 
 // the six values of a layer sit at compile-time offsets f*S from one address (ds_read immediates)
 constexpr int NFW = 6;
 #define W_AT(m, f) wq[(((m) * NFW + (f)) * S)]
-#define W_IR(m) W_AT(m, 0)    // 1/rho
+#define W_IR(m) W_AT(m, 0)    // layer 0: 1/rho; layer m >= 1: rho(m-1)/rho(m), the rescale factor of the carried state (Rayleigh)
 #define W_B(m) W_AT(m, 1)
 #define W_R(m) W_AT(m, 2)
 #define W_D(m) W_AT(m, 3)
@@ -288,6 +288,21 @@ __device__ __forceinline__ void sinhcosh_sp(float x, float *sh, float *ch)
     const float p = __builtin_amdgcn_exp2f(t - 1.0f), q = __builtin_amdgcn_exp2f(-t - 1.0f);
     *sh = p - q;
     *ch = p + q;
+}
+// x <= 0 (evanescent layer): the pair scaled by e^x = e^-|x| from ONE exponential,
+//   one = e^x,  sh = e^x sinh(x) = (e^2x - 1)/2,  ch = e^x cosh(x) = (e^2x + 1)/2.
+// Every term of the layer updates below carries exactly one P factor and one Q factor out of (1, cos, sin), so putting
+// (one, ch, sh) in their place multiplies the whole state by e^x: a positive factor, smooth in c - the secular
+// function keeps its roots and signs, and nothing grows like e^(k d) any more (the reference normalises its vector
+// by its largest entry in every layer for that reason, surfa.f:322-333).  Same cancellation for small |x| as
+// (e^x - e^-x)/2.  A transcendental costs four plain instructions (profiles/r02e/valu_rates.txt).
+__device__ __forceinline__ void sinhcosh_scaled(float x, float *sh, float *ch, float *one)
+{
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269502e+00f);
+    const float e2 = e * e;
+    *one = e;
+    *ch = fmaf(0.5f, e2, 0.5f);
+    *sh = fmaf(0.5f, e2, -0.5f);
 }
 // exact fallback kernel: the same, but as the reference forms them - 0.5 (e^x -+ e^-x) from two separate
 // exponentials (surfa.f:267-269; Love: surfa.f:168-172) - so that they overflow to inf at |x| = 88.72 as its
@@ -337,8 +352,10 @@ __device__ __forceinline__ void sincos_cw(float x, float *sn, float *cs)
 //   h4' = rsinp (sinqr h2 - cosq u1) - cosp (sinqr u2 - cosq h4).
 // The state is carried as (b1, h2..h5): going from layer m to m+1 only rescales it by rho_m/rho_(m+1) (rhoc = rho c^2
 // and c is the same), and the half-space row is applied to rhoc h.  ~40 operations per layer instead of ~100.
-// Vertical wavenumbers ra, rb and their reciprocals come from ONE v_rsq_f32 each; sinh/cosh from two v_exp_f32.
+// Vertical wavenumbers ra, rb and their reciprocals come from ONE v_rsq_f32 each; an evanescent sinh/cosh pair from ONE
+// v_exp_f32, scaled by e^-|x| (sinhcosh_scaled): the secular function comes out multiplied by a positive factor.
 // (The reference's own arithmetic, statement by statement, is delta_rayleigh_ref below: the exact fallback kernel.)
+template <bool PIPE2 = true>
 __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap, const int S,
                                                 const int mmax, const float c, const float T,
                                                 const int start, float &phi)
@@ -354,21 +371,19 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
     const float irhoc0 = (start == 1) ? 0.0f : W_IR(0) * icsq;
     float b1 = (start == 1) ? 1.0f : 0.0f, h2 = (start == 2) ? irhoc0 : 0.0f,
           h3 = (start == 3) ? irhoc0 : 0.0f, h4 = 0.0f, h5 = 0.0f;
-    float rho_prev = 0.0f;
     // software pipeline: layer m+1's six LDS values are in flight while layer m is computed.  The loop
     // is unrolled by two over alternating register sets (no rotation moves between iterations).
-    struct Lyr { float sv, rho, d, ia2, ib2, ir; };
-    auto load = [&](int m) -> Lyr { return {W_B(m), W_R(m), W_D(m), W_IA2(m), W_IB2(m), W_IR(m)}; };
+    struct Lyr { float sv, d, ia2, ib2, rat; };        // rat: rho(m-1)/rho(m), formed when the working stack is built
+    auto load = [&](int m) -> Lyr { return {W_B(m), W_D(m), W_IA2(m), W_IB2(m), W_IR(m)}; };
     // first_tag: only the TOP layer may be liquid in the production kernel (a stack with a liquid layer further down
     // is handed to the exact fallback kernel by the prep kernel's statistics), so the test is made once per evaluation
     auto step = [&](const Lyr &y, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const float sv = y.sv, d = y.d, ia2 = y.ia2, ib2 = y.ib2;
         if (!FIRST) {                                      // into this layer's scale: rhoc_prev / rhoc = rho_prev / rho
-            const float rat = rho_prev * y.ir;
+            const float rat = y.rat;
             h2 *= rat; h3 *= rat; h4 *= rat; h5 *= rat * rat;
         }
-        rho_prev = y.rho;
         const float arga = fmaf(-csq, ia2, 1.0f);                    // 1 - c^2/a^2, surfa.f:211
         // |arga| is clamped away from zero: c == a to the last bit then runs through the oscillatory formulas with
         // ra = 1e-15, which give the reference's degenerate values (rsinp = 0, sinpr = k d, cosp = 1; surfa.f:263-266)
@@ -384,7 +399,7 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             float sinpr, cosp;
             if (fabsf(ra) < ACCUR) { sinpr = wd; cosp = 1.0f; }
             else if (ra < 0.0f) {
-                float sh, ch; sinhcosh_sp(pm, &sh, &ch);
+                float sh, ch, one; sinhcosh_scaled(pm, &sh, &ch, &one);   // every term below has one P factor
                 sinpr = sh / ra;
                 cosp = ch;
             } else {
@@ -406,8 +421,9 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         const float pm = wd * ra;
         const float qm = wd * rb;
         float rsinp, sinpr, cosp, rsinq, sinqr, cosq;
+        float one = 1.0f;                                  // the "1 x 1" of (1, cosp, sinp) x (1, cosq, sinq), see sinhcosh_scaled
         if (arga > 0.0f) {                                 // evanescent P (ra < 0), surfa.f:267-269
-            float sh, ch; sinhcosh_sp(pm, &sh, &ch);
+            float sh, ch; sinhcosh_scaled(pm, &sh, &ch, &one);
             rsinp = -ra * sh; sinpr = sh * ira; cosp = ch;
         } else {                                           // oscillatory P, surfa.f:271-273
             float sn, cs; sincos_cw(pm, &sn, &cs);
@@ -419,21 +435,22 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             rsinq = rb * sn; sinqr = sn * irb; cosq = cs;
             phi += qm;
         } else {
-            float sh, ch; sinhcosh_sp(qm, &sh, &ch);
+            float sh, ch, eq; sinhcosh_scaled(qm, &sh, &ch, &eq);
+            one *= eq;
             rsinq = -rb * sh; sinqr = sh * irb; cosq = ch;
         }
         const float g2 = g * g, g12 = g1 * g1;
         const float u1 = fmaf(g2, b1, fmaf(g + g, h3, -h5));
         const float u2 = fmaf(g12, b1, fmaf(g1 + g1, h3, -h5));
-        const float D = fmaf(-cosp, cosq, 1.0f);
+        const float D = fmaf(-cosp, cosq, one);
         const float t1 = fmaf(rsinq, u1, cosq * h2);            // rsinq u1 + cosq h2
         const float t2 = fmaf(sinqr, u2, -(cosq * h4));         // sinqr u2 - cosq h4
         const float Cx = cosp * rsinq, Cy = cosp * sinqr;
         const float E1 = fmaf(rsinp, t1, fmaf(-Cx, h4, D * u2));
         const float E2 = fmaf(sinpr, t2, fmaf(Cy, h2, D * u1));
-        const float n1 = (b1 - E1) - E2;
-        const float n3 = fmaf(g, E1, fmaf(g1, E2, h3));
-        const float n5 = fmaf(g2, E1, fmaf(g12, E2, h5));
+        const float n1 = fmaf(b1, one, -E1) - E2;
+        const float n3 = fmaf(g, E1, fmaf(g1, E2, h3 * one));
+        const float n5 = fmaf(g2, E1, fmaf(g12, E2, h5 * one));
         const float n2 = fmaf(cosp, t1, sinpr * fmaf(rsinq, h4, cosq * u2));
         const float n4 = fmaf(rsinp, fmaf(sinqr, h2, -(cosq * u1)), -(cosp * t2));
         b1 = n1; h2 = n2; h3 = n3; h4 = n4; h5 = n5;
@@ -447,22 +464,38 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         A = Bq;
         m = 1;
     }
-    while (m + 2 <= last) {
-        const Lyr Bq = load(m + 1);
-        step(A, std::false_type{});
-        A = load(m + 2);
-        step(Bq, std::false_type{});
-        m += 2;
+    if (PIPE2) {
+        while (m + 2 <= last) {
+            const Lyr Bq = load(m + 1);
+            step(A, std::false_type{});
+            A = load(m + 2);
+            step(Bq, std::false_type{});
+            m += 2;
+        }
+    } else {
+        // teams of two lanes: one register set in flight (the instantiation has to stay within 112 VGPRs, see
+        // surfdisp_phase_kernel_v112)
+        while (m + 1 <= last) {
+            const Lyr Bq = load(m + 1);
+            step(A, std::false_type{});
+            A = Bq;
+            m += 1;
+        }
     }
     if (m < last) {
         const Lyr Bq = load(m + 1);
         step(A, std::false_type{});
         A = Bq;
     }
+    // The scaled hyperbolic pairs shrink the state by up to 1/4 per evanescent layer instead of letting it grow by
+    // e^(pm+qm).  Dozens of strongly evanescent layers - where the unscaled product would have left the fp32 range,
+    // the production kernel's cue to hand the stack to the exact kernel - now show as a vanishing state: same cue.
+    if (!(fabsf(b1) + fabsf(h2) + fabsf(h3) + fabsf(h4) + fabsf(h5) > 1.0e-25f)) return __builtin_nanf("");
     // half-space closure, surfa.f:340-354, on (b1, rhoc h2..h4, rhoc^2 h5) with rhoc of the last layer gone through
     // (a itself is not needed: every occurrence is a^2, available as 1/ia2)
-    const float sv = A.sv, irho = A.ir, ia2 = A.ia2;                 // A holds layer mmax-1 here
-    const float rhoc = rho_prev * csq;
+    const float sv = A.sv, ia2 = A.ia2;                              // A holds layer mmax-1 here
+    const float irho = rcp_nr(W_R(last));
+    const float rhoc = (last >= 1 ? W_R(last - 1) : 0.0f) * csq;     // the state is in the scale of the last layer stepped through
     const float arga = fmaf(-csq, ia2, 1.0f);
     float ra = sqrt_hw(fabsf(arga));
     if (arga > 0.0f) ra = -ra;
@@ -606,6 +639,8 @@ __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, con
         if (rb < 0.1e-20f || c == bm) { yv = -wvno * d; z = 0.0f; cosq = 1.0f; }
         else if (c < bm) {
             float sh, ch;
+            // (not the scaled single-exponential pair of the Rayleigh recursion: DLTAR1 does not normalise its vector,
+            // so where THIS product overflows fp32 is where the reference's does - the cue for the exact kernel)
             if constexpr (REFEXP) sinhcosh_ref(q, &sh, &ch); else sinhcosh_sp(q, &sh, &ch);
             yv = sh * rcp_nr(rb);
             z = -rb * rb * yv;
@@ -714,7 +749,7 @@ enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3, ST_NEVILL = 4 };
 //   here (physical models never do), so its speed does not matter; launched after the production kernel with a
 //   grid for the worst case, idle blocks exit at once.
 template <int KIND, int G, bool INDEP, bool FAST = false, bool EXACT = false>
-__global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArgs A)
+__device__ __forceinline__ void phase_body(const PhaseArgs &A)
 {
     extern __shared__ float w_lds[];
     constexpr int S = SD_PHASE_BLOCK / G;                 // stacks (teams) per workgroup
@@ -806,9 +841,19 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
             const LayerV v = layer_derive(r, lnT, hs);
             // the reciprocals are this kernel's own helper values (not the reference's): v_rcp + one Newton
             // step (<= 1 ulp) instead of three IEEE divisions
-            W_IR(i) = rcp_nr(v.rho); W_B(i) = v.b; W_R(i) = v.rho; W_D(i) = v.d;
+            W_B(i) = v.b; W_R(i) = v.rho; W_D(i) = v.d;
+            if (i == 0 || KIND != 2 || EXACT) W_IR(i) = rcp_nr(v.rho);
             W_IA2(i) = (EXACT && KIND == 2) ? v.a : rcp_nr(v.a * v.a);       // exact kernel: a itself (delta_rayleigh_ref)
             W_IB2(i) = (v.b > 0.0f) ? rcp_nr(v.b * v.b) : 0.0f;
+        }
+        if (KIND == 2 && !EXACT) {
+            // the carried state of delta_rayleigh is rescaled by rho(m-1)/rho(m) on entering layer m: formed here, once
+            // per period, from the densities now in the slot - the first stale layer below the refreshed ones included
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int top = nflat < n ? nflat : n - 1;
+            for (int i = 1 + j; i <= top; i += G) W_IR(i) = W_R(i - 1) * rcp_nr(W_R(i));
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -929,7 +974,7 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         float val = 0.0f, phj = 0.0f;
         if (eval) {
             if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, Lcap, S, mmj, cj, Tl, start)
-                                       : delta_rayleigh(wl, Lcap, S, mmj, cj, Tl, start, phj);
+                                       : delta_rayleigh<(G != 2)>(wl, Lcap, S, mmj, cj, Tl, start, phj);
             else           val = EXACT ? delta_love_ref(wl, Lcap, S, mmj, cj, Tl) : delta_love<false>(wl, Lcap, S, mmj, cj, Tl, phj);
         }
         // ---------------------------------------------------------------- team-level decisions
@@ -1270,6 +1315,22 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
         A.nsolved[b] = nsolved;
         if (A.status) A.status[b] = status;
     }
+}
+
+template <int KIND, int G, bool INDEP, bool FAST = false, bool EXACT = false>
+__global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArgs A)
+{
+    phase_body<KIND, G, INDEP, FAST, EXACT>(A);
+}
+// Teams of two lanes are what a caller with several batches in flight gets (SURFDISP_PIPELINED): their wavefronts share
+// SIMDs with the group-velocity kernel's (168 VGPRs), and three of them fit beside one of those only up to 112 VGPRs
+// (3 x 112 + 168 <= 512; measured: at 120 the three-batch headline drops 7 %, profiles/r02e/ab_scaled.txt).  The
+// attribute takes no template-dependent value, hence a second entry point for those teams.
+template <int KIND, int G, bool INDEP, bool FAST = false, bool EXACT = false>
+__global__ __launch_bounds__(SD_PHASE_BLOCK) __attribute__((amdgpu_num_vgpr(112)))
+void surfdisp_phase_kernel_v112(PhaseArgs A)
+{
+    phase_body<KIND, G, INDEP, FAST, EXACT>(A);
 }
 
 // ================================================================================== K2: group
@@ -1947,7 +2008,9 @@ hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 {
     constexpr int S = SD_PHASE_BLOCK / G;
     const size_t lds = EXACT ? sd::phase_exact_lds_bytes(a.Lmax, G) : sd::phase_lds_bytes(a.Lmax, G, a.overlap != 0);
-    auto kern = sd::surfdisp_phase_kernel<KIND, G, INDEP, FAST, EXACT>;
+    void (*kern)(sd::PhaseArgs);
+    if constexpr (G == 2 && !EXACT) kern = sd::surfdisp_phase_kernel_v112<KIND, G, INDEP, FAST, EXACT>;
+    else                            kern = sd::surfdisp_phase_kernel<KIND, G, INDEP, FAST, EXACT>;
     // raise the dynamic-LDS limit of this instantiation only when a launch needs more than any before it (per
     // device): the attribute call costs ~10 us, visible in launch-bound Metropolis loops
     static std::atomic<size_t> lds_set[SD_MAX_DEVICES];

@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void issue_kernel(float *out, int iters, int L
     for (int i = j; i < L; i += 4) {                       // a 10-layer crust/mantle stack, Vs 3.0 -> 4.6
         const float z = (float)i / (float)(L - 1);
         const float b = 3.0f + 1.6f * z, a = 1.76f * b, rho = 0.541f + 0.3601f * a, d = 200.0f / L;
-        W_IR(i) = 1.0f / rho; W_B(i) = b; W_R(i) = rho; W_D(i) = d; W_IA2(i) = 1.0f / (a * a); W_IB2(i) = 1.0f / (b * b);
+        const float zp = (float)(i > 0 ? i - 1 : 0) / (float)(L - 1), rho_up = 0.541f + 0.3601f * 1.76f * (3.0f + 1.6f * zp);
+        W_IR(i) = (i == 0) ? 1.0f / rho : rho_up / rho; W_B(i) = b; W_R(i) = rho; W_D(i) = d; W_IA2(i) = 1.0f / (a * a); W_IB2(i) = 1.0f / (b * b);
     }
     __syncthreads();
     float c = (MODE == 0) ? 3.456f : 3.0f + 1.4f * (float)(slot % 16) / 16.0f + 0.01f * j;
