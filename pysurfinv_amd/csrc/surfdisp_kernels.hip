@@ -258,7 +258,7 @@ SD_HD __forceinline__ LayerV layer_at(const float *__restrict__ mdl, size_t fs, 
 // the six values of a layer sit at compile-time offsets f*S from one address (ds_read immediates)
 constexpr int NFW = 6;
 #define W_AT(m, f) wq[(((m) * NFW + (f)) * S)]
-#define W_IR(m) W_AT(m, 0)    // layer 0: 1/rho; layer m >= 1: rho(m-1)/rho(m), the rescale factor of the carried state (Rayleigh)
+#define W_IR(m) W_AT(m, 0)    // Rayleigh: layer 0 1/rho, layer m >= 1 rho(m-1)/rho(m) (rescale factor of the carried state); Love: 1/(rho b^2)
 #define W_B(m) W_AT(m, 1)
 #define W_R(m) W_AT(m, 2)
 #define W_D(m) W_AT(m, 3)
@@ -268,7 +268,7 @@ constexpr int NFW = 6;
 // ---- fast-but-tight fp32 helpers for the inner recursion --------------------------------------
 // The reference evaluates ~9 IEEE divisions, 2 sqrt and 2-4 libm calls per layer per trial
 // velocity.  Here: reciprocal = v_rcp_f32 + one Newton step (<= 1 ulp), sqrt = v_sqrt_f32 (1 ulp),
-// sinh/cosh = v_exp_f32 on a split argument (~1 ulp), sincos = 3-constant Cody-Waite reduction + minimax
+// sinh/cosh = two v_exp_f32 (~1 ulp), sincos = 3-constant Cody-Waite reduction + minimax
 // polynomials (~1 ulp for |x| < 1e4).  Every one of these perturbs a matrix entry by ~1e-7
 // relative, i.e. like a 1e-7 relative change of a layer's thickness or velocity -- physically
 // nothing; measured end-to-end parity is unchanged.
@@ -278,45 +278,22 @@ __device__ __forceinline__ float rcp_nr(float x)
     return fmaf(r, fmaf(-x, r, 1.0f), r);
 }
 __device__ __forceinline__ float sqrt_hw(float x) { return __builtin_amdgcn_sqrtf(x); }
-// sinh(x), cosh(x) from one split product: 0.5*e^x = 2^(t-1)*(1 + tl*ln2), 0.5*e^-x likewise
+// sinh(x), cosh(x): 0.5 e^x and 0.5 e^-x straight from v_exp_f32 (the 0.5 folded into the exponent)
 __device__ __forceinline__ void sinhcosh_sp(float x, float *sh, float *ch)
 {
     // no low-order correction of x log2(e): e^x and e^-x then carry relative errors +-|x| 9e-8, which for |x| > 1 is a
     // common scale factor of sinh and cosh (the secular function's root does not move) and for |x| < 1 is below one
-    // ulp anyway - golden-case parity unchanged, root search 6 % faster (profiles/r02d/ab_recursion_variants.txt)
+    // ulp anyway - golden-case parity unchanged, root search 6 % faster (profiles/r02d/ab_recursion_variants.txt).
+    // Tried and dropped (r02e): the pair scaled by e^-|x| from ONE exponential ((1 +- e^-2|x|)/2; a transcendental costs
+    // four plain instructions).  The secular function then comes out times s(c) = exp(-sum |x|): same roots and signs,
+    // but s has a square-root kink wherever c crosses a layer velocity and bends the function between them, and the
+    // refine step interpolates - the unscaled function is what the reference's NEVILL sees.  Measured: 4.7 % faster, c
+    // against the exact kernel 5.4e-6 -> 1.2e-5, one sediment fixture entry 5.5e-5; made safe (kink test, unscaled
+    // values for NEVILL, overflow cue from the product of the factors) the gain was gone (profiles/r02e/ab_scaled.txt).
     const float t = x * 1.44269502e+00f;
     const float p = __builtin_amdgcn_exp2f(t - 1.0f), q = __builtin_amdgcn_exp2f(-t - 1.0f);
     *sh = p - q;
     *ch = p + q;
-}
-// x <= 0 (evanescent layer): the pair scaled by e^x = e^-|x| from ONE exponential,
-//   one = e^x,  sh = e^x sinh(x) = (e^2x - 1)/2,  ch = e^x cosh(x) = (e^2x + 1)/2.
-// Every term of the layer updates below carries exactly one P factor and one Q factor out of (1, cos, sin), so putting
-// (one, ch, sh) in their place multiplies the whole state by e^x: a positive factor, smooth in c - the secular
-// function keeps its roots and signs, and nothing grows like e^(k d) any more (the reference normalises its vector
-// by its largest entry in every layer for that reason, surfa.f:322-333).  Same cancellation for small |x| as
-// (e^x - e^-x)/2.  A transcendental costs four plain instructions (profiles/r02e/valu_rates.txt).
-__device__ __forceinline__ void sinhcosh_scaled(float x, float *sh, float *ch, float *one)
-{
-    const float e = __builtin_amdgcn_exp2f(x * 1.44269502e+00f);
-    const float e2 = e * e;
-    *one = e;
-    *ch = fmaf(0.5f, e2, 0.5f);
-    *sh = fmaf(0.5f, e2, -0.5f);
-}
-// exact fallback kernel: the same, but as the reference forms them - 0.5 (e^x -+ e^-x) from two separate
-// exponentials (surfa.f:267-269; Love: surfa.f:168-172) - so that they overflow to inf at |x| = 88.72 as its
-// exp() does, not ln 2 later: where the secular function leaves the fp32 range decides which "root" the reference
-// returns there
-__device__ __forceinline__ void sinhcosh_ref(float x, float *sh, float *ch)
-{
-    const float L2E_HI = 1.44269502e+00f, L2E_LO = 1.92596299e-08f, LN2 = 6.93147182e-01f;
-    const float t = x * L2E_HI;
-    const float corr = fmaf(x, L2E_LO, fmaf(x, L2E_HI, -t)) * LN2;
-    const float p = __builtin_amdgcn_exp2f(t), q = __builtin_amdgcn_exp2f(-t);
-    const float ep = fmaf(p, corr, p), em = fmaf(q, -corr, q);
-    *sh = 0.5f * (ep - em);
-    *ch = 0.5f * (ep + em);
 }
 __device__ __forceinline__ void sincos_cw(float x, float *sn, float *cs)
 {
@@ -352,8 +329,7 @@ __device__ __forceinline__ void sincos_cw(float x, float *sn, float *cs)
 //   h4' = rsinp (sinqr h2 - cosq u1) - cosp (sinqr u2 - cosq h4).
 // The state is carried as (b1, h2..h5): going from layer m to m+1 only rescales it by rho_m/rho_(m+1) (rhoc = rho c^2
 // and c is the same), and the half-space row is applied to rhoc h.  ~40 operations per layer instead of ~100.
-// Vertical wavenumbers ra, rb and their reciprocals come from ONE v_rsq_f32 each; an evanescent sinh/cosh pair from ONE
-// v_exp_f32, scaled by e^-|x| (sinhcosh_scaled): the secular function comes out multiplied by a positive factor.
+// Vertical wavenumbers ra, rb and their reciprocals come from ONE v_rsq_f32 each; sinh/cosh from two v_exp_f32.
 // (The reference's own arithmetic, statement by statement, is delta_rayleigh_ref below: the exact fallback kernel.)
 template <bool PIPE2 = true>
 __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap, const int S,
@@ -399,7 +375,7 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             float sinpr, cosp;
             if (fabsf(ra) < ACCUR) { sinpr = wd; cosp = 1.0f; }
             else if (ra < 0.0f) {
-                float sh, ch, one; sinhcosh_scaled(pm, &sh, &ch, &one);   // every term below has one P factor
+                float sh, ch; sinhcosh_sp(pm, &sh, &ch);
                 sinpr = sh / ra;
                 cosp = ch;
             } else {
@@ -421,9 +397,8 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         const float pm = wd * ra;
         const float qm = wd * rb;
         float rsinp, sinpr, cosp, rsinq, sinqr, cosq;
-        float one = 1.0f;                                  // the "1 x 1" of (1, cosp, sinp) x (1, cosq, sinq), see sinhcosh_scaled
         if (arga > 0.0f) {                                 // evanescent P (ra < 0), surfa.f:267-269
-            float sh, ch; sinhcosh_scaled(pm, &sh, &ch, &one);
+            float sh, ch; sinhcosh_sp(pm, &sh, &ch);
             rsinp = -ra * sh; sinpr = sh * ira; cosp = ch;
         } else {                                           // oscillatory P, surfa.f:271-273
             float sn, cs; sincos_cw(pm, &sn, &cs);
@@ -435,22 +410,21 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             rsinq = rb * sn; sinqr = sn * irb; cosq = cs;
             phi += qm;
         } else {
-            float sh, ch, eq; sinhcosh_scaled(qm, &sh, &ch, &eq);
-            one *= eq;
+            float sh, ch; sinhcosh_sp(qm, &sh, &ch);
             rsinq = -rb * sh; sinqr = sh * irb; cosq = ch;
         }
         const float g2 = g * g, g12 = g1 * g1;
         const float u1 = fmaf(g2, b1, fmaf(g + g, h3, -h5));
         const float u2 = fmaf(g12, b1, fmaf(g1 + g1, h3, -h5));
-        const float D = fmaf(-cosp, cosq, one);
+        const float D = fmaf(-cosp, cosq, 1.0f);
         const float t1 = fmaf(rsinq, u1, cosq * h2);            // rsinq u1 + cosq h2
         const float t2 = fmaf(sinqr, u2, -(cosq * h4));         // sinqr u2 - cosq h4
         const float Cx = cosp * rsinq, Cy = cosp * sinqr;
         const float E1 = fmaf(rsinp, t1, fmaf(-Cx, h4, D * u2));
         const float E2 = fmaf(sinpr, t2, fmaf(Cy, h2, D * u1));
-        const float n1 = fmaf(b1, one, -E1) - E2;
-        const float n3 = fmaf(g, E1, fmaf(g1, E2, h3 * one));
-        const float n5 = fmaf(g2, E1, fmaf(g12, E2, h5 * one));
+        const float n1 = (b1 - E1) - E2;
+        const float n3 = fmaf(g, E1, fmaf(g1, E2, h3));
+        const float n5 = fmaf(g2, E1, fmaf(g12, E2, h5));
         const float n2 = fmaf(cosp, t1, sinpr * fmaf(rsinq, h4, cosq * u2));
         const float n4 = fmaf(rsinp, fmaf(sinqr, h2, -(cosq * u1)), -(cosp * t2));
         b1 = n1; h2 = n2; h3 = n3; h4 = n4; h5 = n5;
@@ -487,10 +461,6 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         step(A, std::false_type{});
         A = Bq;
     }
-    // The scaled hyperbolic pairs shrink the state by up to 1/4 per evanescent layer instead of letting it grow by
-    // e^(pm+qm).  Dozens of strongly evanescent layers - where the unscaled product would have left the fp32 range,
-    // the production kernel's cue to hand the stack to the exact kernel - now show as a vanishing state: same cue.
-    if (!(fabsf(b1) + fabsf(h2) + fabsf(h3) + fabsf(h4) + fabsf(h5) > 1.0e-25f)) return __builtin_nanf("");
     // half-space closure, surfa.f:340-354, on (b1, rhoc h2..h4, rhoc^2 h5) with rhoc of the last layer gone through
     // (a itself is not needed: every occurrence is a^2, available as 1/ia2)
     const float sv = A.sv, ia2 = A.ia2;                              // A holds layer mmax-1 here
@@ -610,46 +580,46 @@ __device__ __noinline__ float delta_rayleigh_ref(const float *wq, const int Lcap
     return (start == 1) ? -bb1 : bb1;
 }
 
-// Love: Thomson-Haskell 2-vector from the half space up, surfa.f:143-179.
-template <bool REFEXP>
+// Love: Thomson-Haskell 2-vector from the half space up, surfa.f:143-179 (production kernel; the reference's own
+// arithmetic is delta_love_ref below).  Per layer: ONE v_rsq_f32 gives rb = sqrt|c^2/b^2 - 1| and 1/rb (|.| clamped away
+// from zero: c == b then runs through the oscillatory formulas with rb = 1e-15, which give the reference's degenerate
+// values y = -k d, z = 0, cosq = 1 of surfa.f:163-165 to 1e-15); 1/(rho b^2) comes from the working stack (the slot the
+// Rayleigh recursion keeps its density ratios in).  Three transcendentals per evanescent layer instead of five.
 __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, const int S,
                                             const int mmax, const float c, const float T, float &phi)
 {
     phi = 0.0f;                                            // see delta_rayleigh
-    const float wvno = 6.2831853f / (c * T);
+    const float wvno = 6.2831853f * rcp_nr(c * T);
     const float csq = c * c;
     const int mh = mmax - 1;
     float bm = W_B(mh);
     float h = W_R(mh) * bm * bm;
     float rb = sqrt_hw(fabsf(fmaf(csq, W_IB2(mh), -1.0f)));          // sqrt|c^2/b^2 - 1|
     float ut = 1.0f, tt = h * rb;
-    // layer m-1's four LDS values are in flight while layer m is computed; unrolled by two over
+    // layer m-1's five LDS values are in flight while layer m is computed; unrolled by two over
     // alternating register sets
-    struct Lyr { float b, d, ib2, r; };
-    auto load = [&](int m) -> Lyr { const int q = m > 0 ? m : 0; return {W_B(q), W_D(q), W_IB2(q), W_R(q)}; };
+    struct Lyr { float b, d, ib2, r, ih; };
+    auto load = [&](int m) -> Lyr { const int q = m > 0 ? m : 0; return {W_B(q), W_D(q), W_IB2(q), W_R(q), W_IR(q)}; };
     auto step = [&](const Lyr &y) {
         bm = y.b;
-        const float d = y.d, ib2 = y.ib2, rho = y.r;
+        const float d = y.d, ib2 = y.ib2, rho = y.r, ih = y.ih;
         if (bm == 0.0f) return;                            // water, surfa.f:152
-        rb = sqrt_hw(fabsf(fmaf(csq, ib2, -1.0f)));
+        const float arg = fmaf(csq, ib2, -1.0f);           // c^2/b^2 - 1: < 0 evanescent
+        const float x = fmaxf(fabsf(arg), 1.0e-30f), irb = __builtin_amdgcn_rsqf(x);
+        rb = x * irb;
         h = rho * bm * bm;
-        const float ih = rcp_nr(h);
         const float q = -wvno * d * rb;
         float yv, z, cosq;
-        if (rb < 0.1e-20f || c == bm) { yv = -wvno * d; z = 0.0f; cosq = 1.0f; }
-        else if (c < bm) {
-            float sh, ch;
-            // (not the scaled single-exponential pair of the Rayleigh recursion: DLTAR1 does not normalise its vector,
-            // so where THIS product overflows fp32 is where the reference's does - the cue for the exact kernel)
-            if constexpr (REFEXP) sinhcosh_ref(q, &sh, &ch); else sinhcosh_sp(q, &sh, &ch);
-            yv = sh * rcp_nr(rb);
-            z = -rb * rb * yv;
+        if (arg < 0.0f) {
+            float sh, ch; sinhcosh_sp(q, &sh, &ch);
+            yv = sh * irb;
+            z = -rb * sh;                                  // -rb^2 y
             cosq = ch;
         } else {
             float sn, cs; sincos_cw(q, &sn, &cs);
-            yv = sn * rcp_nr(rb); z = rb * sn; cosq = cs;
-            phi -= q;
+            yv = sn * irb; z = rb * sn; cosq = cs;
         }
+        phi -= (arg < 0.0f) ? 0.0f : q;
         const float eut = cosq * ut - yv * tt * ih;
         const float ett = h * z * ut + cosq * tt;
         ut = eut; tt = ett;
@@ -842,7 +812,8 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             // the reciprocals are this kernel's own helper values (not the reference's): v_rcp + one Newton
             // step (<= 1 ulp) instead of three IEEE divisions
             W_B(i) = v.b; W_R(i) = v.rho; W_D(i) = v.d;
-            if (i == 0 || KIND != 2 || EXACT) W_IR(i) = rcp_nr(v.rho);
+            if (KIND == 1 && !EXACT) W_IR(i) = rcp_nr(v.rho * v.b * v.b);       // Love, production: 1/(rho b^2)
+            else if (i == 0 || EXACT) W_IR(i) = rcp_nr(v.rho);
             W_IA2(i) = (EXACT && KIND == 2) ? v.a : rcp_nr(v.a * v.a);       // exact kernel: a itself (delta_rayleigh_ref)
             W_IB2(i) = (v.b > 0.0f) ? rcp_nr(v.b * v.b) : 0.0f;
         }
@@ -975,7 +946,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         if (eval) {
             if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, Lcap, S, mmj, cj, Tl, start)
                                        : delta_rayleigh<(G != 2)>(wl, Lcap, S, mmj, cj, Tl, start, phj);
-            else           val = EXACT ? delta_love_ref(wl, Lcap, S, mmj, cj, Tl) : delta_love<false>(wl, Lcap, S, mmj, cj, Tl, phj);
+            else           val = EXACT ? delta_love_ref(wl, Lcap, S, mmj, cj, Tl) : delta_love(wl, Lcap, S, mmj, cj, Tl, phj);
         }
         // ---------------------------------------------------------------- team-level decisions
         const int lm1 = (lane + 63) & 63;
