@@ -43,12 +43,18 @@ def main():
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device(f"cuda:{local}")
+    # BENCH_REHEARSAL=1 (development only, as in bench.py): all ranks share cuda:0 and rendezvous over gloo, to
+    # exercise this entry with several ranks on a one-GPU box
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    dev = torch.device("cuda:0" if rehearsal else f"cuda:{local}")
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
     setting = json.load(open(args.setting)) if args.setting else bench.MCMC_SETTING
     mb = Model1DBatch(setting, device=dev)
     if args.input:
