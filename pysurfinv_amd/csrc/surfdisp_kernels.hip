@@ -447,8 +447,10 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             m += 2;
         }
     } else {
-        // teams of two lanes: one register set in flight (the instantiation has to stay within 112 VGPRs, see
-        // surfdisp_phase_kernel_v112)
+        // Teams of two lanes - what a caller with several batches in flight gets (SURFDISP_PIPELINED) - keep ONE register
+        // set in flight: their wavefronts share SIMDs with the group-velocity kernel's (168 VGPRs), and three of them
+        // fit beside one of those only while 3 x VGPRs + 168 <= 512 (101 this way; measured at 120: the three-batch
+        // headline drops 7 %, profiles/r02e/ab_scaled.txt)
         while (m + 1 <= last) {
             const Lyr Bq = load(m + 1);
             step(A, std::false_type{});
@@ -1293,16 +1295,6 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
 {
     phase_body<KIND, G, INDEP, FAST, EXACT>(A);
 }
-// Teams of two lanes are what a caller with several batches in flight gets (SURFDISP_PIPELINED): their wavefronts share
-// SIMDs with the group-velocity kernel's (168 VGPRs), and three of them fit beside one of those only up to 112 VGPRs
-// (3 x 112 + 168 <= 512; measured: at 120 the three-batch headline drops 7 %, profiles/r02e/ab_scaled.txt).  The
-// attribute takes no template-dependent value, hence a second entry point for those teams.
-template <int KIND, int G, bool INDEP, bool FAST = false, bool EXACT = false>
-__global__ __launch_bounds__(SD_PHASE_BLOCK) __attribute__((amdgpu_num_vgpr(112)))
-void surfdisp_phase_kernel_v112(PhaseArgs A)
-{
-    phase_body<KIND, G, INDEP, FAST, EXACT>(A);
-}
 
 // ================================================================================== K2: group
 // sublayer bookkeeping shared by Rayleigh and Love (surfa.f:781-822 / 412-446): layers are split
@@ -1979,9 +1971,7 @@ hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 {
     constexpr int S = SD_PHASE_BLOCK / G;
     const size_t lds = EXACT ? sd::phase_exact_lds_bytes(a.Lmax, G) : sd::phase_lds_bytes(a.Lmax, G, a.overlap != 0);
-    void (*kern)(sd::PhaseArgs);
-    if constexpr (G == 2 && !EXACT) kern = sd::surfdisp_phase_kernel_v112<KIND, G, INDEP, FAST, EXACT>;
-    else                            kern = sd::surfdisp_phase_kernel<KIND, G, INDEP, FAST, EXACT>;
+    auto kern = sd::surfdisp_phase_kernel<KIND, G, INDEP, FAST, EXACT>;
     // raise the dynamic-LDS limit of this instantiation only when a launch needs more than any before it (per
     // device): the attribute call costs ~10 us, visible in launch-bound Metropolis loops
     static std::atomic<size_t> lds_set[SD_MAX_DEVICES];
