@@ -20,7 +20,7 @@
 enum Op { FMA = 0, MUL, ADD, EXP, RSQ, RCP, SIN, CNDMASK, BFI, CMP, MAX, MOV, XOR, CVT, FMA64, MUL64, ADD64,
           DSREAD, MIX_LAYER,
           CNDMASK_S, CNDMASK_NEG, AND, ADDU, LSHL, RNDNE, FMAC, FMAMK, MULLIT, SUB, MAXABS, FMANEG, CMP_S, DPP, DSREAD2,
-          MIN, MED3, ANDOR, LSHLOR, FREXP, LDEXP, FLOOR, SQRT, MULNEG, CMPCLASS, READLANE, CNDMASK_E64V, MIX_CND_V, MIX_CND_S, MIX_EXP, MIX_CMPCND, MIX_BFI, NOPS };
+          MIN, MED3, ANDOR, LSHLOR, FREXP, LDEXP, FLOOR, SQRT, MULNEG, CMPCLASS, READLANE, CNDMASK_E64V, MIX_CND_V, MIX_CND_S, MIX_EXP, MIX_CMPCND, MIX_BFI, PKFMA, PKMUL, PKADD, NOPS };
 static const char *names[] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_exp_f32", "v_rsq_f32", "v_rcp_f32", "v_sin_f32",
                               "v_cndmask_b32", "v_bfi_b32", "v_cmp_lt_f32", "v_max_f32", "v_mov_b32", "v_xor_b32",
                               "v_cvt_i32_f32", "v_fma_f64", "v_mul_f64", "v_add_f64", "ds_read_b32",
@@ -33,7 +33,7 @@ static const char *names[] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_exp_f32"
                               "v_mul_f32_e64 -a", "v_cmp_class_f32", "v_readlane_b32", "v_cndmask_b32_e64 (vcc)",
                               "1 v_cndmask_b32 (vcc) + 7 v_fma_f32, per instruction", "1 v_cndmask_b32_e64 (SGPR pair) + 7 v_fma_f32",
                               "1 v_exp_f32 + 7 v_fma_f32", "v_cmp_lt_f32 vcc; v_cndmask vcc; 6 v_fma_f32",
-                              "1 v_bfi_b32 + 7 v_fma_f32"};
+                              "1 v_bfi_b32 + 7 v_fma_f32", "v_pk_fma_f32 (two fp32 per lane)", "v_pk_mul_f32", "v_pk_add_f32"};
 
 template <int OP>
 __global__ __launch_bounds__(1024) void rate_kernel(float *out, long long *cyc, int iters, float seed)
@@ -248,6 +248,18 @@ __global__ __launch_bounds__(1024) void rate_kernel(float *out, long long *cyc, 
 #undef R
 #undef Q
 #undef P
+        } else if (OP == PKFMA) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(d[i]) : "v"(cd), "v"(bd));
+            REP16(X)
+#undef X
+        } else if (OP == PKMUL) {
+#define X(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d[i]) : "v"(cd));
+            REP16(X)
+#undef X
+        } else if (OP == PKADD) {
+#define X(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d[i]) : "v"(cd));
+            REP16(X)
+#undef X
         } else if (OP == MIX_LAYER) {
             // the instruction mix of one layer of the Rayleigh recursion on its evanescent path
             // (ISA of surfdisp_phase_kernel<2,4,...>): 2 v_rsq + 4 v_exp among ~85 plain instructions; 96 here
@@ -331,7 +343,7 @@ int main(int argc, char **argv)
                 C(FMA64) C(MUL64) C(ADD64) C(DSREAD) C(MIX_LAYER)
                 C(CNDMASK_S) C(CNDMASK_NEG) C(AND) C(ADDU) C(LSHL) C(RNDNE) C(FMAC) C(FMAMK) C(MULLIT) C(SUB) C(MAXABS) C(FMANEG)
                 C(CMP_S) C(DPP) C(DSREAD2) C(MIN) C(MED3) C(ANDOR) C(LSHLOR) C(FREXP) C(LDEXP) C(FLOOR) C(SQRT) C(MULNEG)
-                C(CMPCLASS) C(READLANE) C(CNDMASK_E64V) C(MIX_CND_V) C(MIX_CND_S) C(MIX_EXP) C(MIX_CMPCND) C(MIX_BFI)
+                C(CMPCLASS) C(READLANE) C(CNDMASK_E64V) C(MIX_CND_V) C(MIX_CND_S) C(MIX_EXP) C(MIX_CMPCND) C(MIX_BFI) C(PKFMA) C(PKMUL) C(PKADD)
 #undef C
             }
             const double n_inst = (double)iters * (op == MIX_LAYER ? 96.0 : 128.0);
