@@ -447,6 +447,8 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
             m += 2;
         }
     } else {
+        // (also the opt-in fast scan's instantiations: their extra scan state put teams of four at 133 VGPRs = three
+        // wavefronts per SIMD, 27 M solves/s with one batch in flight; single-buffered 122 = four, 36 M.)
         // Teams of two lanes - what a caller with several batches in flight gets (SURFDISP_PIPELINED) - keep ONE register
         // set in flight: their wavefronts share SIMDs with the group-velocity kernel's (168 VGPRs), and three of them
         // fit beside one of those only while 3 x VGPRs + 168 <= 512 (101 this way; measured at 120: the three-batch
@@ -947,7 +949,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         float val = 0.0f, phj = 0.0f;
         if (eval) {
             if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, Lcap, S, mmj, cj, Tl, start)
-                                       : delta_rayleigh<(G != 2)>(wl, Lcap, S, mmj, cj, Tl, start, phj);
+                                       : delta_rayleigh<(G != 2) && !FAST>(wl, Lcap, S, mmj, cj, Tl, start, phj);
             else           val = EXACT ? delta_love_ref(wl, Lcap, S, mmj, cj, Tl) : delta_love(wl, Lcap, S, mmj, cj, Tl, phj);
         }
         // ---------------------------------------------------------------- team-level decisions
