@@ -289,7 +289,7 @@ __device__ __forceinline__ void sinhcosh_sp(float x, float *sh, float *ch)
     // but s has a square-root kink wherever c crosses a layer velocity and bends the function between them, and the
     // refine step interpolates - the unscaled function is what the reference's NEVILL sees.  Measured: 4.7 % faster, c
     // against the exact kernel 5.4e-6 -> 1.2e-5, one sediment fixture entry 5.5e-5; made safe (kink test, unscaled
-    // values for NEVILL, overflow cue from the product of the factors) the gain was gone (profiles/r02e/ab_scaled.txt).
+    // values for NEVILL, overflow cue from the product of the factors) the gain was gone (profiles/r02e/ab_experiments.txt).
     const float t = x * 1.44269502e+00f;
     const float p = __builtin_amdgcn_exp2f(t - 1.0f), q = __builtin_amdgcn_exp2f(-t - 1.0f);
     *sh = p - q;
@@ -452,7 +452,7 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
         // Teams of two lanes - what a caller with several batches in flight gets (SURFDISP_PIPELINED) - keep ONE register
         // set in flight: their wavefronts share SIMDs with the group-velocity kernel's (168 VGPRs), and three of them
         // fit beside one of those only while 3 x VGPRs + 168 <= 512 (101 this way; measured at 120: the three-batch
-        // headline drops 7 %, profiles/r02e/ab_scaled.txt)
+        // headline drops 7 %, profiles/r02e/ab_experiments.txt)
         while (m + 1 <= last) {
             const Lyr Bq = load(m + 1);
             step(A, std::false_type{});
