@@ -688,3 +688,40 @@ def test_default_mode_agrees_with_strict_mode_at_full_size(hip, kind, B, L):
     assert np.abs(cd.astype(np.float64) / cs - 1.0).max() < 1e-5
     eu = np.abs(ud.astype(np.float64) / us - 1.0)
     assert eu.max() < 1e-4 and np.quantile(eu, 0.999) < 5e-6
+
+
+def test_entries_may_be_called_from_several_threads(hip):
+    """include/surfdisp.h: the solve entries keep no state between calls and may be called from several threads.  Four
+    host threads (ctypes releases the GIL) hammer the host-buffer entry and the f2py-shaped single-stack entry at the same
+    time, Rayleigh and Love; every result equals the one obtained serially, bit for bit."""
+    import threading
+    from pysurfinv_amd import synth, fast_surf
+    per = synth.default_periods(12)
+    jobs = [(synth.synth_models(700 + 37 * i, 9, seed=300 + i), 2 - (i % 2)) for i in range(8)]
+    serial = [hip.forward_batch(m, per, kind) for m, kind in jobs]
+    one = jobs[0][0][0]
+    per200 = np.zeros(200, np.float32); per200[:len(per)] = per          # f2py shape: cvper is real*4[200]
+    f_serial = fast_surf.fast_surf(9, 2, one[0], one[1], one[2], one[3], one[4], per200, len(per))
+    errors = []
+
+    def worker(t):
+        try:
+            for it in range(6):
+                i = (t * 3 + it) % len(jobs)
+                c, u, st = hip.forward_batch(jobs[i][0], per, jobs[i][1])
+                if not (np.array_equal(c, serial[i][0]) and np.array_equal(u, serial[i][1], equal_nan=True)
+                        and np.array_equal(st, serial[i][2])):
+                    errors.append(("batch", t, it, i))
+                f = fast_surf.fast_surf(9, 2, one[0], one[1], one[2], one[3], one[4], per200, len(per))
+                if not all(np.array_equal(a, b) for a, b in zip(f, f_serial)):
+                    errors.append(("fast_surf", t, it))
+        except Exception as e:                                   # noqa: BLE001 - reported through the list
+            errors.append(("exception", t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not any(th.is_alive() for th in threads)
+    assert not errors, errors[:4]
