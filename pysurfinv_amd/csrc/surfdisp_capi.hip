@@ -20,6 +20,7 @@ std::atomic<double *> g_dbg{nullptr};    // developer hook, see surfdisp_debug_b
 struct EnvKnobs {
     int team = 0;                 // SURFDISP_TEAM
     size_t overlap_max = 64u * 1024u;   // SURFDISP_OVERLAP_MAX
+    size_t lds_budget = 44u * 1024u;    // SURFDISP_LDS_BUDGET (developer knob): root-search LDS per 256 lanes
     float refine_wtol = 1.2e-3f;  // SURFDISP_WTOL
     float refine_atol = 1.0e-6f;  // SURFDISP_ATOL
     float phimax = 0.7853982f;    // SURFDISP_SCAN_PHASE (fast scan only; developer knob)
@@ -30,6 +31,7 @@ struct EnvKnobs {
     {
         if (const char *e = getenv("SURFDISP_TEAM")) team = atoi(e);
         if (const char *e = getenv("SURFDISP_OVERLAP_MAX")) overlap_max = (size_t)atol(e);
+        if (const char *e = getenv("SURFDISP_LDS_BUDGET")) lds_budget = (size_t)atol(e);
         if (const char *e = getenv("SURFDISP_WTOL")) refine_wtol = (float)atof(e);
         if (const char *e = getenv("SURFDISP_ATOL")) refine_atol = (float)atof(e);
         if (const char *e = getenv("SURFDISP_SCAN_PHASE")) phimax = (float)atof(e);
@@ -86,15 +88,15 @@ Carve carve(void *base, int B, int Lmax, int P)
     return c;
 }
 
-int pick_team(int B, int Lmax, bool need_ratio = true)
+int pick_team(int B, int Lmax, bool need_ratio = true, bool pipelined = false)
 {
     int G = g_team_override.load(std::memory_order_relaxed);
     if (G == 0) G = knobs().team;
     if (G == 0) {
-        // measured on MI355X (scripts/dev_overlap.py): batches of 16 384 stacks and
-        // more want ~4 wavefronts per SIMD (262 144 lanes on 256 CUs x 4 SIMDs), smaller ones ~2, tiny
-        // ones a whole wavefront per stack (latency); never fewer than 2 lanes per stack
-        const long target = (B >= 16384) ? 262144L : 131072L;
+        // measured on MI355X (scripts/sweep_team.py, profiles/r02e/sweep_team.txt): at least three wavefronts per
+        // SIMD (196 608 lanes on 256 CUs x 4 SIMDs) whatever the batch size, tiny batches a whole wavefront per
+        // stack (latency); never fewer than 2 lanes per stack
+        const long target = 196608L;
         G = 2;
         while (G < 64 && (long)B * G < target) G *= 2;
     }
@@ -103,18 +105,23 @@ int pick_team(int B, int Lmax, bool need_ratio = true)
     int p2 = 1;
     while (p2 * 2 <= G) p2 *= 2;
     G = p2;
-    // working stack of 256/G teams must fit LDS so that two workgroups share a CU: with the ellipticity
-    // snapshot slot (Rayleigh c+U calls) both slots within 64 KB, without it (phase-only, Love) 80 KB
-    const size_t per256 = 256 / SD_PHASE_BLOCK;        // the budgets below are per 256 lanes
-    if (need_ratio) { while (G < 64 && G >= 4 && sd::phase_lds_bytes(Lmax, G, true) * per256 > 64u * 1024u) G *= 2; }
-    while (G < 64 && sd::phase_lds_bytes(Lmax, G, false) * per256 > 80u * 1024u) G *= 2;
-    if (need_ratio) { while (G < 64 && G >= 4 && sd::phase_lds_bytes(Lmax, G, true) * per256 > 64u * 1024u) G *= 2; }
+    // The working stacks of a workgroup's 256/G teams (two slots each where the ellipticity passes ride in the next
+    // period's scan, Rayleigh c+U with teams of >= 4 lanes) are what limits the workgroups per CU: keep them within
+    // 44 KB per 256 lanes, i.e. at least three workgroups = wavefronts per SIMD, normally four - a wider team
+    // wastes fewer evaluations than a half-empty SIMD costs (scripts/sweep_team.py, profiles/r02e/sweep_team.txt:
+    // up to 1.5 x on batches of 30-64-layer stacks against the r02d budgets of 64 / 80 KB).
+    const size_t per256 = 256 / SD_PHASE_BLOCK;        // the budget is per 256 lanes
+    // (a caller that keeps another batch in flight - SURFDISP_PIPELINED, the joint Rayleigh + Love plan - has the other
+    // stream's wavefronts to fill a SIMD: there the narrower team's fewer evaluations win, 64 KB = two workgroups)
+    const size_t budget = pipelined ? (knobs().lds_budget * 16) / 11 : knobs().lds_budget;
+    auto lds_of = [&](int g) { return sd::phase_lds_bytes(Lmax, g, need_ratio && g >= 4) * per256; };
+    while (G < 64 && lds_of(G) > budget) G *= 2;
     return G;
 }
 
 // The second LDS slot (ellipticity of period k evaluated inside the first scan pass of period k+1) saves
-// one pass per period but doubles the workgroup's LDS: only while two workgroups still fit a CU
-// (measured: on at 49 KB is 7-19 % faster than off, on at 74 KB / 147 KB is 9 % / 38 % slower).
+// one pass per period but doubles the workgroup's LDS (measured: on at 49 KB is 7-19 % faster than off, on at
+// 74 KB / 147 KB is 9 % / 38 % slower): on whenever the two slots fit - pick_team sized the team for that.
 static bool use_overlap(int Lmax, int G)
 {
     const size_t cap = knobs().overlap_max;
@@ -220,7 +227,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     // independent mode has B*P root searches in flight: size the teams for that many; a caller that
     // keeps a second batch in flight (SURFDISP_PIPELINED) has twice the stacks on the chip
     const long units = (indep ? (long)B * P : (long)B) * (pipelined ? 2 : 1);
-    const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax, kind == SURFDISP_KIND_RAYLEIGH && !phase_only);
+    const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax, kind == SURFDISP_KIND_RAYLEIGH && !phase_only, pipelined);
 
     sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl, P, indep ? w.nsolved : nullptr, w.fsafe, w.ovf, w.fb_count};
     if (ev) SD_HIP(hipEventRecord(ev[0], s));
@@ -228,7 +235,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     if (ev) SD_HIP(hipEventRecord(ev[1], s));
     const float wtol = kn.refine_wtol, atol = kn.refine_atol, phimax = kn.phimax;
     sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, phase_only ? nullptr : w.ratio, w.nsolved, status, wtol, atol,
-                     fastscan ? 1 : 0, w.fsafe, (!phase_only && use_overlap(Lmax, G)) ? 1 : 0, phimax,
+                     fastscan ? 1 : 0, w.fsafe, (kind == SURFDISP_KIND_RAYLEIGH && !phase_only && use_overlap(Lmax, G)) ? 1 : 0, phimax,
                      w.ovf, w.fb_count, w.fb_list, kn.balance >= 0 ? kn.balance : (pipelined ? 0 : 1), strict ? 1 : 0};
 #ifdef SD_WAVECLOCK
     ph.wclk = reinterpret_cast<unsigned long long *>(g_dbg.load(std::memory_order_relaxed));

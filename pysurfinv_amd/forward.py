@@ -243,8 +243,8 @@ class JointPlan:
         for s in (self.s_ray, self.s_love):
             s.wait_stream(cur)                       # inputs were produced on the caller's stream
         with torch.cuda.stream(self.s_ray):
-            cR, uR, sR = self.ray.run(model, periods, kind=_lib.KIND_RAYLEIGH, nlay=nlay)
+            cR, uR, sR = self.ray.run(model, periods, kind=_lib.KIND_RAYLEIGH, nlay=nlay, pipelined=True)
         with torch.cuda.stream(self.s_love):
-            cL, uL, sL = self.love.run(model, periods, kind=_lib.KIND_LOVE, nlay=nlay)
+            cL, uL, sL = self.love.run(model, periods, kind=_lib.KIND_LOVE, nlay=nlay, pipelined=True)
         cur.wait_stream(self.s_ray); cur.wait_stream(self.s_love)
         return dict(cR=cR, uR=uR, cL=cL, uL=uL, statusR=sR, statusL=sL)
