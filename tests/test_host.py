@@ -37,6 +37,14 @@ def test_workspace_and_team_heuristics():
     assert L.surfdisp_get_team(65536, 10) == 4           # the bench workload
     g = L.surfdisp_get_team(1 << 20, 200)                # LDS bound forces wider teams
     assert g >= 8 and 4 * 200 * (256 // g) * 4 <= 80 * 1024
+    # the workgroup's working stacks stay within 44 KB of LDS per 256 lanes (two slots of 6 floats per layer + 24 per team
+    # for Rayleigh c+U calls with teams of >= 4 lanes, which is what surfdisp_get_team describes)
+    for B, Lmax in ((65536, 10), (32768, 30), (65536, 30), (16384, 64), (25600, 96), (4096, 20), (100, 96)):
+        g = L.surfdisp_get_team(B, Lmax)
+        slots = 2 if g >= 4 else 1
+        assert (slots * 6 * Lmax + 24) * (256 // g) * 4 <= 44 * 1024 or g == 64, (B, Lmax, g)
+        assert B * g >= 196608 or g == 64, (B, Lmax, g)
+    assert L.surfdisp_get_team(32768, 30) == 16 and L.surfdisp_get_team(4096, 20) == 64
     assert L.surfdisp_set_team(3) == _lib.ERR_INVALID
     assert L.surfdisp_set_team(16) == 0 and L.surfdisp_get_team(5, 5) == 16
     L.surfdisp_set_team(0)
