@@ -154,7 +154,10 @@ int surfdisp_events_elapsed_ms(void *start, void *stop, float *ms);
  *          to the CALLER's layer values (the chain factors of the attenuation correction
  *          calcul.f:122-126 and of the earth flattening flat1.f:44-62 are applied); zero for water
  *          layers, layers below the effective half space and unsolved periods.  dcda, dcdr may be
- *          NULL; Love has no dcda (written as zeros if given).  Same workspace as (3). */
+ *          NULL; Love has no dcda (written as zeros if given).  Workspace: surfdisp_kernels_workspace_bytes
+ *          (the partials are accumulated in a layer-major scratch inside it and transposed into the rows at the end:
+ *          coalesced); a workspace of only surfdisp_workspace_bytes is accepted and takes the direct, slower route. */
+size_t surfdisp_kernels_workspace_bytes(int B, int Lmax, int P);
 int surfdisp_forward_kernels_device(void *stream, int B, int Lmax, const int *nlay,
                                     const float *model, int P, const float *per, int kind,
                                     float *c, float *u, int *status,

@@ -30,7 +30,7 @@ EXPORTS = (
     "surfdisp_forward_batch_device_events", "surfdisp_events_create", "surfdisp_events_destroy",
     "surfdisp_events_elapsed_ms", "surfdisp_params_to_model_device",
     "surfdisp_params_to_model_thermal_device", "surfdisp_thermal_scratch_bytes",
-    "surfdisp_forward_kernels_device", "surfdisp_workspace_fallback_count", "surfdisp_set_team", "surfdisp_get_team",
+    "surfdisp_forward_kernels_device", "surfdisp_kernels_workspace_bytes", "surfdisp_workspace_fallback_count", "surfdisp_set_team", "surfdisp_get_team",
     "surfdisp_device_count", "surfdisp_abi_version", "surfdisp_last_error",
     "surfdisp_kernel_name",
 )
@@ -71,6 +71,8 @@ def lib() -> ctypes.CDLL:
                                          ctypes.c_int, fp, ctypes.c_int, fp, fp, ip]
     L.surfdisp_workspace_bytes.restype = ctypes.c_size_t
     L.surfdisp_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.surfdisp_kernels_workspace_bytes.restype = ctypes.c_size_t
+    L.surfdisp_kernels_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.surfdisp_forward_batch_device.restype = ctypes.c_int
     L.surfdisp_forward_batch_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp,
                                                 ctypes.c_int, vp, ctypes.c_int, vp, vp, vp,

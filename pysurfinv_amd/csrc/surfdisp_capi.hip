@@ -189,6 +189,15 @@ size_t surfdisp_workspace_bytes(int B, int Lmax, int P)
     return carve(nullptr, B, Lmax, P).total;
 }
 
+// workspace of surfdisp_forward_kernels_device with room for the layer-major scratch [3][Lmax][P][B] the analytic
+// partials are accumulated in (the lanes of a wavefront - consecutive stacks, one period - then touch consecutive
+// words instead of rows 4 P Lmax bytes apart); a workspace of only surfdisp_workspace_bytes still works, slower
+size_t surfdisp_kernels_workspace_bytes(int B, int Lmax, int P)
+{
+    if (B < 1 || Lmax < 2 || P < 1) return 0;
+    return align_up(carve(nullptr, B, Lmax, P).total) + (size_t)3 * Lmax * P * B * sizeof(float);
+}
+
 // introspection: how many stacks (or (stack, period) units in independent mode) the last solve that used this
 // workspace handed to the exact fallback kernel.  Waits for `stream`.
 int surfdisp_workspace_fallback_count(void *stream, const void *workspace, int B, int Lmax, int P, int *count)
@@ -250,8 +259,18 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
 #else
     double *gdbg = g_dbg.load(std::memory_order_relaxed);
 #endif
-    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, gdbg, kb, ka, kr};
+    // analytic partials: through the layer-major scratch when the caller's workspace has room for it
+    float *kscr = nullptr;
+    if (kb && workspace_bytes >= surfdisp_kernels_workspace_bytes(B, Lmax, P))
+        kscr = reinterpret_cast<float *>(static_cast<char *>(workspace) + align_up(w.total));
+    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, gdbg, kb, ka, kr, kscr};
     if (!phase_only) SD_HIP(sd::launch_group(s, kind, ga));
+    if (!phase_only && kscr) {
+        const size_t arr = (size_t)Lmax * P * B;
+        SD_HIP(sd::launch_kern_transpose(s, kscr, kb, B, P, Lmax));
+        if (ka) SD_HIP(sd::launch_kern_transpose(s, kscr + arr, ka, B, P, Lmax));
+        if (kr) SD_HIP(sd::launch_kern_transpose(s, kscr + 2 * arr, kr, B, P, Lmax));
+    }
     sd::FinishArgs fa{B, P, w.ct, phase_only ? nullptr : w.ut, c, phase_only ? nullptr : u,
                       indep ? w.nsolved : nullptr, w.nl, status};
     SD_HIP(sd::launch_finish(s, fa));

@@ -57,6 +57,7 @@ struct GroupArgs {
     float *u;             // [P][B]
     double *dbg;          // nullptr, or [B][P][16] intermediate values (developer builds)
     float *kb, *ka, *kr;  // nullptr, or [B][P][Lmax] analytic partials dc/dVs, dc/dVp, dc/drho
+    float *kscr;          // nullptr, or the layer-major scratch [3][Lmax][P][B] they are accumulated in (coalesced)
 };
 
 struct FinishArgs {
@@ -90,6 +91,7 @@ size_t phase_exact_lds_bytes(int Lmax, int G);
 int phase_exact_team(int Lmax);                          // lanes per stack of the exact fallback kernel
 hipError_t launch_phase_exact(hipStream_t s, int kind, bool independent, const PhaseArgs &a);
 hipError_t launch_finish(hipStream_t s, const FinishArgs &a);
+hipError_t launch_kern_transpose(hipStream_t s, const float *scr, float *out, int B, int P, int Lmax);
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a);
 hipError_t launch_phase(hipStream_t s, int kind, int G, bool independent, const PhaseArgs &a);
 hipError_t launch_group(hipStream_t s, int kind, const GroupArgs &a);

@@ -1348,7 +1348,17 @@ SD_HD __forceinline__ Drop drop_group(const float *__restrict__ mdl, size_t fs, 
 // caller's derivatives are with respect to its own Vs, Vp, rho, so each layer carries the chain
 // factors of calcul.f:122-126 and flat1.f:44-62:
 //   b = b_ref (1 + qsq) f,  a = a_ref (1 + qsq 4/3 b_ref^2/a_ref^2) f,  rho = rho_ref r
-struct KernRow { float *b, *a, *r; };      // this (stack, period)'s rows [Lmax], or nullptrs
+// this (stack, period)'s partials of layer i at b[i * stride] (a, r likewise; nullptrs when not wanted): stride 1 = the
+// caller's [B][P][Lmax] rows directly; stride P*B = the layer-major scratch of the kernels workspace, where the lanes of
+// a wavefront (consecutive stacks, one period) touch consecutive words - the rows are then written by
+// surfdisp_kern_transpose_kernel
+struct KernRow {
+    float *b, *a, *r;
+    size_t stride;
+    SD_HD float &B_(int i) const { return b[(size_t)i * stride]; }
+    SD_HD float &A_(int i) const { return a[(size_t)i * stride]; }
+    SD_HD float &R_(int i) const { return r[(size_t)i * stride]; }
+};
 struct Chain { float dbdb, dadb, dada, rfac; };
 SD_HD __forceinline__ Chain chain_of(const LayerRaw &r, float lnT, bool is_halfspace)
 {
@@ -1375,9 +1385,9 @@ SD_HD __forceinline__ void kern_add_rayleigh(const KernRow &ko, int jl, const Ch
     const double db = 2.0 * v.rho * v.b * c * (dldm - 2.0 * dldl) / wvno;
     const double da = 2.0 * v.rho * v.a * c * dldl / wvno;
     const double dr = (c / wvno) * (dldr + xlamb * dldl / v.rho + xmu * dldm / v.rho);
-    ko.b[jl] += (float)(db * ch.dbdb + da * ch.dadb);
-    if (ko.a) ko.a[jl] += (float)(da * ch.dada);
-    if (ko.r) ko.r[jl] += (float)(dr * ch.rfac);
+    ko.B_(jl) += (float)(db * ch.dbdb + da * ch.dadb);
+    if (ko.a) ko.A_(jl) += (float)(da * ch.dada);
+    if (ko.r) ko.R_(jl) += (float)(dr * ch.rfac);
 }
 
 // ---- Rayleigh, surfa.f:714-1192 ---------------------------------------------------------------
@@ -1495,7 +1505,7 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
                                                const Drop dr, float wvno, float wvnosq, float omegsq,
                                                double y[4], double z[4], bool do_y,
                                                double xnorm, double bbn, RInt &acc,
-                                               const KernRow ko = KernRow{nullptr, nullptr, nullptr}, float c = 0.0f)
+                                               const KernRow ko = KernRow{nullptr, nullptr, nullptr, 1}, float c = 0.0f)
 {
 #pragma clang fp contract(off)   // both sweeps must see identical coefficients
     LayerRaw nraw = layer_load(mdl, fs, (size_t)dr.hs_layer * B + b);
@@ -1597,7 +1607,7 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
 template <bool KERN = false>
 SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
                                 float T, float c, float ratio, double *dbg = nullptr,
-                                const KernRow ko = KernRow{nullptr, nullptr, nullptr})
+                                const KernRow ko = KernRow{nullptr, nullptr, nullptr, 1})
 {
 #pragma clang fp contract(off)
     const float lnT = logf(1.0f / T);
@@ -1652,8 +1662,8 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
                 const Chain ch = chain_of(wraw, lnT, false);
                 const double dldl = -(double)wvnosq * (ra * ra) * (ra * ra) * fac2;
                 const double dldr = (double)omegsq * (fac1 + fac2);
-                if (ko.a) ko.a[0] += (float)(2.0 * top.rho * top.a * c * dldl / wvno * ch.dada);
-                if (ko.r) ko.r[0] += (float)((c / wvno) * (dldr + (double)top.a * top.a * dldl) * ch.rfac);
+                if (ko.a) ko.A_(0) += (float)(2.0 * top.rho * top.a * c * dldl / wvno * ch.dada);
+                if (ko.r) ko.R_(0) += (float)((c / wvno) * (dldr + (double)top.a * top.a * dldl) * ch.rfac);
             }
         }
     }
@@ -1765,9 +1775,9 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
     if (KERN) {                                                       // surfa.f:1203-1207
         const float idldk = 1.0f / (-2.0f * (wvno * s1 + s2));
         for (int i = 0; i <= dr.hs_layer; ++i) {
-            ko.b[i] *= idldk;
-            if (ko.a) ko.a[i] *= idldk;
-            if (ko.r) ko.r[i] *= idldk;
+            ko.B_(i) *= idldk;
+            if (ko.a) ko.A_(i) *= idldk;
+            if (ko.r) ko.R_(i) *= idldk;
         }
     }
     return (wvno * s1 + s2) / (omega * s0);                           // surfa.f:1186
@@ -1776,7 +1786,7 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
 // ---- Love, surfa.f:374-606 (all fp32, as the reference) --------------------------------------
 template <bool KERN = false>
 SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
-                            float T, float c, const KernRow ko = KernRow{nullptr, nullptr, nullptr})
+                            float T, float c, const KernRow ko = KernRow{nullptr, nullptr, nullptr, 1})
 {
     const float lnT = logf(1.0f / T);
     int ndiv = 5;
@@ -1797,13 +1807,13 @@ SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, i
         const Chain ch = chain_of(raw, lnT, jl == n - 1);
         const float dldm = -(wvnosq * dm + sm);
         const float dldr = omegsq * dm;
-        ko.b[jl] += 2.0f * v.rho * v.b * c * dldm / wvno * ch.dbdb;
-        if (ko.r) ko.r[jl] += (c / wvno) * (dldr + v.b * v.b * dldm) * ch.rfac;
+        ko.B_(jl) += 2.0f * v.rho * v.b * c * dldm / wvno * ch.dbdb;
+        if (ko.r) ko.R_(jl) += (c / wvno) * (dldr + v.b * v.b * dldm) * ch.rfac;
     };
     float ut0 = 1.0f;
     for (int attempt = 0; attempt < 16; ++attempt) {
         float ut = ut0;
-        if (kern) for (int i = 0; i <= dr.hs_layer; ++i) { ko.b[i] = 0.0f; if (ko.r) ko.r[i] = 0.0f; }
+        if (kern) for (int i = 0; i <= dr.hs_layer; ++i) { ko.B_(i) = 0.0f; if (ko.r) ko.R_(i) = 0.0f; }
         const float covb = c / hsv.b;
         const float hh = hsv.rho * hsv.b * hsv.b;
         const float rbh = wvno * sqrtf(fabsf(covb * covb - 1.0f));
@@ -1878,7 +1888,7 @@ SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, i
         if (overflow) { ut0 = ut0 / 1.0e5f; continue; }
         if (kern) {                                                   // surfa.f:581-585
             const float idldk = 1.0f / (-2.0f * wvno * sumi1);
-            for (int i = 0; i <= dr.hs_layer; ++i) { ko.b[i] *= idldk; if (ko.r) ko.r[i] *= idldk; }
+            for (int i = 0; i <= dr.hs_layer; ++i) { ko.B_(i) *= idldk; if (ko.r) ko.R_(i) *= idldk; }
         }
         sumi0 = sumi0 / (ut * ut);
         sumi1 = sumi1 / (ut * ut);
@@ -1902,16 +1912,27 @@ void surfdisp_group_kernel(GroupArgs A)
     const int b = (int)(idx % B), k = (int)(idx / B);       // a wavefront = 64 stacks, one period
     const size_t o = idx;                                   // period-major [P][B]: coalesced
     const int n = A.nl[b];
-    KernRow ko{nullptr, nullptr, nullptr};
-    if (KERN) {                                             // caller's [B][P][Lmax] rows, zero-filled
-        const size_t ro = ((size_t)b * P + k) * A.Lmax;
-        ko.b = A.kb + ro;
-        ko.a = (KIND == 2 && A.ka) ? A.ka + ro : nullptr;
-        ko.r = A.kr ? A.kr + ro : nullptr;
+    KernRow ko{nullptr, nullptr, nullptr, 1};
+    if (KERN) {                                             // this unit's rows, zero-filled
+        float *ka_row;
+        if (A.kscr) {                                       // layer-major scratch [3][Lmax][P][B]: coalesced
+            const size_t arr = (size_t)A.Lmax * P * B;
+            ko.stride = (size_t)P * B;
+            ko.b = A.kscr + idx;
+            ka_row = A.ka ? A.kscr + arr + idx : nullptr;
+            ko.r = A.kr ? A.kscr + 2 * arr + idx : nullptr;
+        } else {                                            // the caller's [B][P][Lmax] rows (small workspace)
+            const size_t ro = ((size_t)b * P + k) * A.Lmax;
+            ko.stride = 1;
+            ko.b = A.kb + ro;
+            ka_row = A.ka ? A.ka + ro : nullptr;
+            ko.r = A.kr ? A.kr + ro : nullptr;
+        }
+        ko.a = (KIND == 2) ? ka_row : nullptr;              // Love has no dc/dVp: its rows stay zero
         for (int i = 0; i < A.Lmax; ++i) {
-            ko.b[i] = 0.0f;
-            if (A.ka) A.ka[ro + i] = 0.0f;
-            if (ko.r) ko.r[i] = 0.0f;
+            ko.B_(i) = 0.0f;
+            if (ka_row) ka_row[(size_t)i * ko.stride] = 0.0f;
+            if (ko.r) ko.R_(i) = 0.0f;
         }
     }
     if (n < 2 || k >= A.nsolved[b]) { A.u[o] = 0.0f; return; }
@@ -1959,6 +1980,27 @@ __global__ __launch_bounds__(256) void surfdisp_finish_kernel(FinishArgs A)
             dst[(size_t)b0 * P + i] = tile[bl * PS + k];
         }
         __syncthreads();
+    }
+}
+
+// K2b: the analytic partials from the layer-major scratch [Lmax][P*B] (unit index u = k*B + b) to the caller's
+// [B][P][Lmax] rows, 64 units x 64 layers per workgroup through an LDS tile: reads run along the units, writes along
+// the layers.
+__global__ __launch_bounds__(256) void surfdisp_kern_transpose_kernel(const float *__restrict__ scr, float *__restrict__ out,
+                                                                      int B, int P, int Lmax)
+{
+    __shared__ float tile[64][65];
+    const int nbb = (B + 63) / 64;
+    const int k = blockIdx.x / nbb, b0 = (blockIdx.x % nbb) * 64, i0 = blockIdx.y * 64;
+    const size_t PB = (size_t)P * B;
+    for (int t = threadIdx.x; t < 64 * 64; t += 256) {
+        const int il = t / 64, bl = t % 64;
+        if (i0 + il < Lmax && b0 + bl < B) tile[il][bl] = scr[(size_t)(i0 + il) * PB + (size_t)k * B + b0 + bl];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 64 * 64; t += 256) {
+        const int bl = t / 64, il = t % 64;
+        if (i0 + il < Lmax && b0 + bl < B) out[((size_t)(b0 + bl) * P + k) * Lmax + i0 + il] = tile[il][bl];
     }
 }
 
@@ -2080,6 +2122,13 @@ hipError_t launch_phase(hipStream_t s, int kind, int G, bool independent, const 
 {
     if (independent) return kind == 2 ? launch_phase_k<2, true>(s, a, G) : launch_phase_k<1, true>(s, a, G);
     return kind == 2 ? launch_phase_k<2, false>(s, a, G) : launch_phase_k<1, false>(s, a, G);
+}
+
+hipError_t launch_kern_transpose(hipStream_t s, const float *scr, float *out, int B, int P, int Lmax)
+{
+    const dim3 grid((unsigned)(P * ((B + 63) / 64)), (unsigned)((Lmax + 63) / 64));
+    hipLaunchKernelGGL(surfdisp_kern_transpose_kernel, grid, dim3(256), 0, s, scr, out, B, P, Lmax);
+    return hipGetLastError();
 }
 
 hipError_t launch_finish(hipStream_t s, const FinishArgs &a)

@@ -126,6 +126,7 @@ class BatchPlan:
                                  or nlay.device != self.device):
             raise ValueError("nlay must be int32 [B] on the same device")
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._last_ws = self.workspace
         args = [ctypes.c_void_p(stream), self.B, self.L,
                 ctypes.c_void_p(nlay.data_ptr() if nlay is not None else 0),
                 ctypes.c_void_p(model.data_ptr()), self.P, ctypes.c_void_p(periods.data_ptr()),
@@ -152,11 +153,11 @@ class BatchPlan:
         n = ctypes.c_int(0)
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
         with self.torch.cuda.device(self.device):
-            _lib.check(_lib.lib().surfdisp_workspace_fallback_count(ctypes.c_void_p(stream), ctypes.c_void_p(self.workspace.data_ptr()),
+            _lib.check(_lib.lib().surfdisp_workspace_fallback_count(ctypes.c_void_p(stream), ctypes.c_void_p(getattr(self, '_last_ws', self.workspace).data_ptr()),
                                                                     self.B, self.L, self.P, ctypes.byref(n)))
         return int(n.value)
 
-    def run_kernels(self, model, periods, kind=2, nlay=None, want_vp=True, want_rho=True):
+    def run_kernels(self, model, periods, kind=2, nlay=None, want_vp=True, want_rho=True, small_workspace=False):
         """Forward solve + analytic partial derivatives of the phase velocity
         (``surfdisp_forward_kernels_device``): returns (c, u, status, dcdb, dcda, dcdr) with the
         partials float32 [B, P, L] = d c(period) / d (Vs | Vp | rho) of input layer i (``None`` where
@@ -176,11 +177,19 @@ class BatchPlan:
         dcdr = mk() if want_rho else None
         ptr = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        if small_workspace:                            # the direct route into the rows (tests compare the two)
+            ws, ws_bytes = self.workspace, self.ws_bytes
+        else:
+            if getattr(self, "kworkspace", None) is None:      # + the layer-major scratch of the partials, kept for reuse
+                self.kws_bytes = int(_lib.lib().surfdisp_kernels_workspace_bytes(self.B, self.L, self.P))
+                self.kworkspace = torch.empty(self.kws_bytes, dtype=torch.uint8, device=self.device)
+            ws, ws_bytes = self.kworkspace, self.kws_bytes
+        self._last_ws = ws
         with torch.cuda.device(self.device):
             rc = _lib.lib().surfdisp_forward_kernels_device(
                 ctypes.c_void_p(stream), self.B, self.L, ptr(nlay), ptr(model), self.P, ptr(periods), int(kind),
                 ptr(self.c), ptr(self.u), ptr(self.status), ptr(dcdb), ptr(dcda), ptr(dcdr),
-                ptr(self.workspace), self.ws_bytes)
+                ptr(ws), ws_bytes)
         _lib.check(rc)
         return self.c, self.u, self.status, dcdb, dcda, dcdr
 

@@ -188,3 +188,29 @@ def test_senskernelpert_class_fd_and_analytic_agree():
     b = senskernel.SensKernelPert(dfg, wtype="L", method="analytic")
     sc = np.abs(b.kernel["Vs"][:, thick]).max()
     assert np.abs(a.kernel["Vs"][:, thick] - b.kernel["Vs"][:, thick]).max() < 0.03 * sc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [2, 1])
+def test_partials_through_the_scratch_equal_the_direct_route(kind):
+    """surfdisp_forward_kernels_device accumulates the analytic partials in a layer-major scratch of its workspace
+    (surfdisp_kernels_workspace_bytes: coalesced) and transposes them into the caller's [B][P][Lmax] rows; with a
+    workspace of only surfdisp_workspace_bytes it writes the rows directly.  Same sums in the same order: bit-identical,
+    ragged layer counts, a water layer and unsolved periods included."""
+    import torch
+    from pysurfinv_amd import forward, synth, _lib
+    B, L, P = 300, 37, 11
+    assert _lib.lib().surfdisp_kernels_workspace_bytes(B, L, P) >= _lib.lib().surfdisp_workspace_bytes(B, L, P) + 3 * L * P * B * 4
+    m = synth.synth_models(B, L, seed=4, noise=0.08, monotone=False)
+    m[:20, 1, 0] = 0.0; m[:20, 0, 0] = 1.475; m[:20, 2, 0] = 1.027; m[:20, 4, 0] = 1e-4; m[:20, 3, 0] = 2.0
+    nlay = np.random.default_rng(2).integers(3, L + 1, B).astype(np.int32)
+    per = torch.from_numpy(synth.default_periods(P)).cuda()
+    mt, nt = torch.from_numpy(m).cuda(), torch.from_numpy(nlay).cuda()
+    plan = forward.BatchPlan(B, L, P)
+    big = [t.clone() if t is not None else None for t in plan.run_kernels(mt, per, kind=kind, nlay=nt)]
+    small = plan.run_kernels(mt, per, kind=kind, nlay=nt, small_workspace=True)
+    for a, b in zip(big, small):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    assert float(big[3].abs().max()) > 0.0
