@@ -20,6 +20,8 @@ nstack = ncase = npat = novf = 0
 bad_cases = []
 while time.time() < T_END:
     L = int(rng.integers(2, 48)); B = int(rng.integers(64, 2048)) * (16 if STRICT else 1); kind = int(rng.integers(1, 3))
+    if os.environ.get("SOAK_KIND"):                        # one wave type only (1 Love, 2 Rayleigh)
+        kind = int(os.environ["SOAK_KIND"])
     noise = float(rng.choice([0.02, 0.05, 0.1, 0.2])); mono = bool(rng.random() < 0.6)
     model = synth.synth_models(B, L, seed=int(rng.integers(1 << 30)), noise=noise, monotone=mono,
                                total_thickness=float(rng.choice([60., 120., 200., 400.])))
