@@ -74,7 +74,7 @@ Carve carve(void *base, int B, int Lmax, int P)
     char *p = static_cast<char *>(base);
     size_t off = 0;
     Carve c;
-    c.mdl = reinterpret_cast<float *>(p + off);     off += align_up((size_t)10 * Lmax * B * sizeof(float));
+    c.mdl = reinterpret_cast<float *>(p + off);     off += align_up((size_t)9 * Lmax * B * sizeof(float));      // sd::NF staged fields
     c.ratio = reinterpret_cast<float *>(p + off);   off += align_up((size_t)P * B * sizeof(float));
     c.ct = reinterpret_cast<float *>(p + off);      off += align_up((size_t)P * B * sizeof(float));
     c.ut = reinterpret_cast<float *>(p + off);      off += align_up((size_t)P * B * sizeof(float));

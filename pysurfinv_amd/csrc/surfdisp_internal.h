@@ -11,7 +11,7 @@ struct PrepArgs {
     int B, Lmax;
     const int *nlay;      // [B] or nullptr
     const float *model;   // [B][5][Lmax] (vp, vs, rho, h, qsinv) as handed over by the caller
-    float *mdl;           // [10][Lmax][B] SoA: the five inputs + five flattening factors
+    float *mdl;           // [9][Lmax][B] SoA: vp, vs, rho, 1/Qs + five flattening factors
     int *nl;              // [B] validated layer count, 0 = bad model
     int P;
     int *nsolved_init;    // nullptr, or [B]: set to P (independent mode reduces it with atomicMin)

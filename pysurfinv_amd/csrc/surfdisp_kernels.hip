@@ -7,7 +7,7 @@
 // formula or a semantic rule is taken from it.
 //
 // Pipeline for one (batch, wave type):
-//   K0 surfdisp_prep_kernel   : AoS model[B][5][L] -> SoA mdl[10][L][B]; per-layer earth-flattening
+//   K0 surfdisp_prep_kernel   : AoS model[B][5][L] -> SoA mdl[9][L][B]; per-layer earth-flattening
 //                               factors computed ONCE per stack (flat1.f:33-69 recomputes them
 //                               40x per solve), validation.
 //   K1 surfdisp_phase_kernel  : phase velocities.  A TEAM of G lanes (G = 1..64, one wavefront holds
@@ -50,7 +50,8 @@ constexpr float ACCUR   = 1.e-8f;        // surfa.f:191-192
 constexpr float CLUSTER_DC = 1.0e-4f;    // spacing of clustered refine points (teams of <= 4 lanes)
 
 // SoA field ids of mdl[NF][Lmax][B]
-enum { F_VP = 0, F_VS, F_RHO, F_H, F_QS, F_DIF, F_QQQ, F_DFL, F_HSF, F_HSR, NF = 10 };
+// (the raw thickness is not staged: nothing downstream reads it, only the flattened one, F_DFL)
+enum { F_VP = 0, F_VS, F_RHO, F_QS, F_DIF, F_QQQ, F_DFL, F_HSF, F_HSR, NF = 9 };
 
 SD_HD __forceinline__ bool fin(float x) { return fabsf(x) <= 3.402823466e38f; }   // finite, host+device
 SD_HD __forceinline__ float pwr_of(int kind) { return kind == 1 ? 5.0f : 2.2750f; }  // flat1.f:27-28
@@ -116,7 +117,7 @@ SD_HD inline void prep_stack(const PrepArgs &A, const int b)
             const size_t o = (size_t)i * B + b;
             const size_t fs = (size_t)Lmax * B;
             mdl[F_VP * fs + o] = vp;   mdl[F_VS * fs + o] = vs;   mdl[F_RHO * fs + o] = rho;
-            mdl[F_H * fs + o] = h;     mdl[F_QS * fs + o] = qs;
+            mdl[F_QS * fs + o] = qs;
             mdl[F_DIF * fs + o] = dif; mdl[F_QQQ * fs + o] = qqq; mdl[F_DFL * fs + o] = dfl;
             mdl[F_HSF * fs + o] = hsf; mdl[F_HSR * fs + o] = hsr;
             r_i = r_n;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void surfdisp_prep_kernel(PrepArgs A)
         bmax = fmaxf(bmax, 1.06f * vs * fmaxf(dif, hsf));
         const size_t o = (size_t)i * B + b;
         mdl[F_VP * fs + o] = vp;   mdl[F_VS * fs + o] = vs;   mdl[F_RHO * fs + o] = rho;
-        mdl[F_H * fs + o] = h;     mdl[F_QS * fs + o] = qs;
+        mdl[F_QS * fs + o] = qs;
         mdl[F_DIF * fs + o] = dif; mdl[F_QQQ * fs + o] = qqq; mdl[F_DFL * fs + o] = dfl;
         mdl[F_HSF * fs + o] = hsf; mdl[F_HSR * fs + o] = hsr;
     }

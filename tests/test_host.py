@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_workspace_and_team_heuristics():
     from pysurfinv_amd import _lib
     L = _lib.lib()
-    assert L.surfdisp_workspace_bytes(65536, 10, 20) >= 65536 * (10 * 10 + 20) * 4
+    assert L.surfdisp_workspace_bytes(65536, 10, 20) >= 65536 * (9 * 10 + 20) * 4
     assert L.surfdisp_workspace_bytes(0, 10, 20) == 0
     L.surfdisp_set_team(0)
     os.environ.pop("SURFDISP_TEAM", None)
