@@ -732,6 +732,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     const int tid = threadIdx.x;
 #ifdef SD_WAVECLOCK
     const unsigned long long wclk0 = __builtin_amdgcn_s_memrealtime();
+    // shader cycles (s_memtime) of this wavefront: whole loop, evaluations of the secular function, stack rebuilds
+    const unsigned long long wcyc0 = __builtin_readcyclecounter();
+    unsigned long long wcyc_eval = 0, wcyc_build = 0, wcyc_pre = 0, wpasses = 0;
 #endif
     const int lane = tid & 63;
     const int slot = tid / G;
@@ -884,6 +887,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
 
     int wprio = -1;
     while (__any(st != ST_DONE)) {
+#ifdef SD_WAVECLOCK
+        const unsigned long long wp0 = __builtin_readcyclecounter();
+#endif
         // The SIMD arbitrates between its wavefronts by priority, then age: left alone, the four wavefronts of a
         // SIMD finish one after the other and the last one runs alone for a seventh of the kernel.  Let a wavefront
         // that is behind (period index of its first team) go first: 2.39 -> 2.15 ms for one bench batch (profiles/r02c).
@@ -949,11 +955,19 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             eval = (G == 1) || (j < 2);
         }
         float val = 0.0f, phj = 0.0f;
+#ifdef SD_WAVECLOCK
+        const unsigned long long we0 = __builtin_readcyclecounter();
+        wcyc_pre += we0 - wp0;                                 // priority, trial velocities, layer dropping
+        ++wpasses;
+#endif
         if (eval) {
             if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, Lcap, S, mmj, cj, Tl, start)
                                        : delta_rayleigh<(G != 2) && !FAST>(wl, Lcap, S, mmj, cj, Tl, start, phj);
             else           val = EXACT ? delta_love_ref(wl, Lcap, S, mmj, cj, Tl) : delta_love(wl, Lcap, S, mmj, cj, Tl, phj);
         }
+#ifdef SD_WAVECLOCK
+        wcyc_eval += __builtin_readcyclecounter() - we0;
+#endif
         // ---------------------------------------------------------------- team-level decisions
         const int lm1 = (lane + 63) & 63;
         const float sc = __shfl(cj, lm1), sv_ = __shfl(val, lm1);
@@ -1244,6 +1258,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         if (fatal) {
             nsolved = 0; k = 0; status = SURFDISP_NUMERIC; st = ST_DONE; ell_pend = false; solved = false; failed = false;
         }
+#ifdef SD_WAVECLOCK
+        const unsigned long long wb0 = __builtin_readcyclecounter();
+#endif
         if (solved) {
             if (j == 0) {
                 A.c[(size_t)k * B + b] = croot;                // period-major: coalesced across teams
@@ -1264,6 +1281,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 nodrop = no_drop_possible(p0c);
             }
         }
+#ifdef SD_WAVECLOCK
+        wcyc_build += __builtin_readcyclecounter() - wb0;      // store of the root, next period's set-up, stack rebuild
+#endif
         if (failed) {
             status = (k == 0) ? SURFDISP_NOROOT : SURFDISP_PARTIAL;
             st = ST_DONE;
@@ -1272,7 +1292,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
 #ifdef SD_WAVECLOCK
     if (!EXACT && A.wclk && (threadIdx.x & 63) == 0) {
         const size_t w = (size_t)blockIdx.x * (SD_PHASE_BLOCK / 64) + (threadIdx.x >> 6);
-        A.wclk[2 * w] = wclk0; A.wclk[2 * w + 1] = __builtin_amdgcn_s_memrealtime();
+        A.wclk[6 * w] = wclk0; A.wclk[6 * w + 1] = __builtin_amdgcn_s_memrealtime();
+        A.wclk[6 * w + 2] = __builtin_readcyclecounter() - wcyc0; A.wclk[6 * w + 3] = wcyc_eval;
+        A.wclk[6 * w + 4] = wcyc_build; A.wclk[6 * w + 5] = wpasses | (wcyc_pre << 20);
     }
 #endif
     if (INDEP) {
