@@ -44,25 +44,7 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS, CLOCK_HZ = 1024, 2.4e9 # 256 CUs x 4 SIMDs, max clock
 VALU_PEAK = SIMDS * CLOCK_HZ / 2.0            # wave-level VALU instructions / s (one per 2 cycles per SIMD)
 
-# the continental model of the Metropolis legs: sediment + 4-coefficient crust + 5-coefficient mantle + reference
-# mantle = 96 layers, 13 random-walk parameters (the setting the driver golden vectors were captured with)
-MCMC_SETTING = {
-    'Sediment': {'H': [2., 'abs_pos', 1.5, 0.1], 'Vs': [[1.5, 'abs', 0.5, 0.05], [2.2, 'abs', 0.5, 0.05]]},
-    'Crust': {'H': [35., 'abs', 10., 1.0],
-              'Vs': [[3.4, 'abs', 0.3, 0.02], [3.6, 'abs', 0.3, 0.02], [3.8, 'abs', 0.3, 0.02], [3.9, 'abs', 0.3, 0.02]]},
-    'Mantle': {'H': 160., 'Vs': [[4.4, 'abs', 0.4, 0.02], [4.35, 'abs', 0.4, 0.02], [4.4, 'abs', 0.4, 0.02],
-                                 [4.5, 'abs', 0.4, 0.02], [4.6, 'abs', 0.4, 0.02]]},
-    'Info': {'modelType': 'MCInv', 'refLayer': True},
-}
-MCMC_PERIODS = [8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 50, 60, 70, 80]
-C5_SETTING = {
-    'OceanWater': {'H': 2.6},
-    'OceanSedimentCascadia': {'H': [0.3, 'abs', 0.2, 0.03]},
-    'OceanCrust': {'H': 4.4, 'Vs': [3.25, 3.94]},
-    'OceanMantleHybrid': {'BottomDepth': 200, 'Conversion': 'Ritzwoller', 'ThermAge': [4, 'rel_pos', 200, 0.4],
-                          'Vs': [[0, 'abs', 0.2, 0.01], [0, 'abs', 0.2, 0.01], [0, 'abs', 0.2, 0.01], [0, 'abs', 0.1, 0.01]]},
-    'Info': {'modelType': 'MCInv', 'period': 10, 'refLayer': False},
-}
+from pysurfinv_amd.settings import C5_SETTING, MCMC_PERIODS, MCMC_SETTING   # noqa: E402  (no torch import)
 
 
 def lib_hash():
@@ -117,37 +99,76 @@ def cpu_baseline(per, c_gpu, u_gpu):
 
 
 # ------------------------------------------------------------------------------------------------ helpers
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is only a launcher.  It
+    starts N rank processes through torch.distributed.run (one per GPU, 127.0.0.1 rendezvous on a free port) as a CHILD
+    process - no exec, and this parent never imports torch or touches HIP - passes their output through (rank 0
+    prints the JSON line) and exits with the children's return code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print(f"bench.py launcher: pid {os.getpid()} starts {n} ranks, torch imported in the launcher: {'torch' in sys.modules}",
+          file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 class Runtime:
     def __init__(self, args):
         import torch
         self.torch = torch
         self.rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.local_rank = local_rank
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        if args.gpus != self.world and self.world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        if args.gpus != self.world:
+            raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={self.world}: launch one rank per GPU")
+        # BENCH_REHEARSAL (development / tests only): "1" = all ranks share cuda:0 and rendezvous over gloo, to exercise the
+        # N > 1 path on a one-GPU box; "cpu" = gloo and no device at all (only --workload launchcheck runs there)
+        mode = os.environ.get("BENCH_REHEARSAL", "")
+        self.rehearsal = mode in ("1", "cpu")
+        self.cpu_only = mode == "cpu"
         self.dist = None
+        self.backend = None
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            # nccl == RCCL on ROCm.  BENCH_REHEARSAL=1 (development only): all ranks share cuda:0 and
-            # rendezvous over gloo, to exercise this code path on a one-GPU box.
-            if os.environ.get("BENCH_REHEARSAL") == "1":
+            if self.rehearsal:
                 local_rank = 0
                 dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
             else:
+                # nccl == RCCL on ROCm
                 dist.init_process_group(backend="nccl", rank=self.rank, world_size=self.world,
                                         device_id=torch.device(f"cuda:{local_rank}"))
             self.dist = dist
-        self.dev = torch.device(f"cuda:{local_rank}")
-        torch.cuda.set_device(self.dev)
-        self.rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+            self.backend = dist.get_backend()
+        self.dev = torch.device("cpu") if self.cpu_only else torch.device(f"cuda:{local_rank}")
+        if not self.cpu_only:
+            torch.cuda.set_device(self.dev)
+
+    @property
+    def group_ranks(self):
+        """World size as the process group itself reports it (RCCL ranks on a GPU node)."""
+        return int(self.dist.get_world_size()) if self.dist is not None else 1
+
+    def stamp(self, line):
+        line.update({"rccl_ranks": self.group_ranks,
+                     "collective_backend": ("rccl (torch.distributed nccl)" if self.backend == "nccl" else self.backend)})
+        return line
 
     def barrier(self):
-        self.torch.cuda.synchronize(self.dev)
+        if not self.cpu_only:
+            self.torch.cuda.synchronize(self.dev)
         if self.dist is not None:
             self.dist.barrier()
-        self.torch.cuda.synchronize(self.dev)
+        if not self.cpu_only:
+            self.torch.cuda.synchronize(self.dev)
 
     def max_over_ranks(self, *vals):
         """MAX over ranks of each value (every timing of the line goes through here)."""
@@ -175,6 +196,45 @@ class Runtime:
             fn()
         self.barrier()
         return self.max_over_ranks(time.perf_counter() - t0)[0]
+
+
+def leg_roofline(leg, live_ms, alg_bytes_per_launch, kernel_prefix="surfdisp_phase_kernel<2,", team=None):
+    """Roofline block of a side leg: its dominant kernel (the Rayleigh root search), VALU-bound.  achieved = wave-level
+    VALU instructions per launch (rocprofv3 --pmc pass of THIS library build on this leg, profiles/traffic_<leg>.json,
+    written by scripts/profile_leg.sh + scripts/summarise_leg.py) / the LIVE average duration of that kernel (HIP events
+    on its stream inside this run); the HBM figure north_star asks for is beside it."""
+    live_s = live_ms * 1e-3
+    hbm = alg_bytes_per_launch / live_s / 1e9 if live_s > 0 else None
+    roof = {"bound": "valu", "kernel": None, "unit": "wave-level VALU instructions/s", "peak": VALU_PEAK,
+            "achieved": None, "frac": None, "traffic": None, "live_kernel_ms": live_ms,
+            "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS if hbm else None,
+                    "algorithmic_bytes_per_launch": alg_bytes_per_launch}}
+    tfile = os.path.join(ROOT, "profiles", f"traffic_{leg}.json")
+    if not os.path.exists(tfile):
+        roof["note"] = f"profiles/traffic_{leg}.json absent: no counter pass for this leg"
+        return roof
+    try:
+        tj = json.load(open(tfile))
+        cands = {k: v for k, v in tj["kernels"].items() if k.startswith(kernel_prefix) and "valu_wave_instructions" in v
+                 and (team is None or k.split(",")[1] == str(team))}
+        if not cands:
+            roof["note"] = f"no {kernel_prefix}..> instantiation" + (f" with teams of {team}" if team else "") + " in the profile"
+            return roof
+        name = max(cands, key=lambda k: cands[k].get("pct_of_gpu_time", 0.0))
+        v = cands[name]
+        here = lib_hash()
+        roof.update({"kernel": name, "achieved": v["valu_wave_instructions"] / live_s,
+                     "frac": v["valu_wave_instructions"] / live_s / VALU_PEAK,
+                     "traffic": v.get("hbm_bytes_per_launch"),
+                     "frac_measured_issue_costs": (v["valu_issue_frac_measured_costs"] * (v["kernel_cycles"] / CLOCK_HZ) / live_s
+                                                   if "valu_issue_frac_measured_costs" in v else None),
+                     "profile_kernel_avg_ms": v.get("avg_us", 0.0) / 1e3,
+                     "lane_utilisation": v.get("lane_utilisation"), "mean_waves_per_simd": v.get("mean_waves_per_simd"),
+                     "pmc_profile": tj.get("round"), "pmc_lib_sha256_16": tj.get("lib_sha256_16"), "this_lib_sha256_16": here,
+                     "pmc_matches_this_build": tj.get("lib_sha256_16") == here})
+    except Exception as e:
+        roof["note"] = f"profiles/traffic_{leg}.json unreadable: {e}"
+    return roof
 
 
 # ------------------------------------------------------------------------------------------------ workloads
@@ -293,20 +353,9 @@ def workload_forward(rt, args):
 
 
 def _mcmc_setup(rt, n_points, chains):
-    """Continental model + synthetic per-point observations: the model's own curve at a random 'true' parameter vector
-    per point (prior draw shrunk towards the start model), 1 % uncertainty."""
-    torch = rt.torch
-    from pysurfinv_amd.layers_batch import Model1DBatch
-    from pysurfinv_amd.brownian import TorchProposer
-    mb = Model1DBatch(MCMC_SETTING, device=rt.dev)
-    pr = TorchProposer(mb.spec, rt.dev, seed=100 + rt.rank)
-    v0 = torch.as_tensor(mb.spec.v0, dtype=torch.float64, device=rt.dev)[None, :]
-    truth = v0 + 0.3 * (pr.reset(n_points) - v0)
-    c_true, st = mb.forward(truth, periods=MCMC_PERIODS)
-    c0, _ = mb.forward(v0, periods=MCMC_PERIODS)
-    c_true = torch.where((st != 0)[:, None] | (c_true < 0.01), c0.expand_as(c_true), c_true)   # unsolved draw: start model's curve
-    c_obs = c_true.double().cpu().numpy()
-    return mb, c_obs, 0.01 * c_obs
+    """Continental model + synthetic per-point observations (pysurfinv_amd.settings.synthetic_observations)."""
+    from pysurfinv_amd.settings import synthetic_observations
+    return synthetic_observations(n_points, rt.dev, seed=100 + rt.rank)
 
 
 def workload_grid(rt, args, steps=None, warmup=None):
@@ -340,10 +389,20 @@ def workload_grid(rt, args, steps=None, warmup=None):
 
     setup()
     n0 = mc.n_forward
+    from pysurfinv_amd import _lib, forward
+    mc.event_ring = forward.EventRing(K)                   # HIP events on the launch stream around the solver's kernels
     elapsed = rt.timed(step, K, W)
+    kms = mc.event_ring.kernel_ms().mean(axis=0)
+    mc.event_ring = None
     L = int(mb.to_model(state["p"][:4])[0].shape[2])
     acc_rate, = rt.max_over_ranks(float(state["acc"].double().mean()))
+    per_rank_ms, = rt.max_over_ranks(elapsed / K * 1e3)
+    team = int(_lib.lib().surfdisp_get_team(C, L))         # (Rayleigh c+U sizing; phase-only calls may choose narrower)
     return {"metric": "Metropolis steps/s, model3D grid share (BASELINE configs[3])", "unit": "steps/s",
+            "ms_per_step_max_over_ranks": per_rank_ms,
+            "kernel_ms": {"prep": kms[0], "phase": kms[1], "finish": kms[2],
+                          "how": "HIP events on the launch stream around the solver's kernels of the K timed lock steps"},
+            "roofline": leg_roofline("grid", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * C),
             "value": rt.world * C * K / elapsed, "forward_solves_per_s": rt.world * C * K / elapsed,
             "ms_per_step": elapsed / K * 1e3, "steps": K, "warmup": W, "n_gpus": rt.world, "scaling": "weak",
             "config": {"workload": "BASELINE configs[3] share per GPU: 512 points x 50 chains, 96-layer continental model, "
@@ -363,10 +422,17 @@ def workload_mcmc(rt, args, steps=None, warmup=None):
            "config": {"workload": "BASELINE configs[2]: one point, 100 chains in lock step (100 000 steps = 1000 lock steps), "
                                   "96-layer continental model, 19 periods, Rayleigh phase-only misfit", "chains": 100}}
     mc = MetropolisBatch(mb.spec, mb.to_model, MCMC_PERIODS, c_obs[0], unc[0], device=rt.dev, seed=3 + rt.rank)
+    from pysurfinv_amd import forward
     mc.run(100, 4); rt.barrier()
+    mc.event_ring = forward.EventRing(K)
     t0 = time.perf_counter(); mc.run(100, K + 1); rt.barrier()
     dt, = rt.max_over_ranks(time.perf_counter() - t0)
-    out.update({"value": rt.world * 100 * K / dt, "ms_per_lock_step": dt / K * 1e3, "steps": K})
+    kms = mc.event_ring.kernel_ms().mean(axis=0)
+    mc.event_ring = None
+    L = int(mb.to_model(mc.reset(2))[0].shape[2])
+    out.update({"value": rt.world * 100 * K / dt, "ms_per_lock_step": dt / K * 1e3, "steps": K, "scaling": "weak",
+                "kernel_ms": {"prep": kms[0], "phase": kms[1], "finish": kms[2]},
+                "roofline": leg_roofline("mcmc", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * 100)})
     try:
         mc.run_graphed(100, 8); rt.barrier()
         t0 = time.perf_counter(); mc.run_graphed(100, 4 * K + 2); rt.barrier()
@@ -399,7 +465,14 @@ def workload_c5(rt, args, steps=None, warmup=None):
     t_gen = rt.timed(gen, K, W)
     L = int(st["model"].shape[2])
     plan = forward.JointPlan(B, L, 20, device=rt.dev)
-    t_joint = rt.timed(lambda: plan.run(st["model"], per, nlay=st["nlay"]), K, W)
+    ringR, ringL = forward.EventRing(K), forward.EventRing(K)
+    cnt = {"i": 0}
+
+    def joint():
+        plan.run(st["model"], per, nlay=st["nlay"], events=(ringR.slot(cnt["i"]), ringL.slot(cnt["i"])))
+        cnt["i"] += 1
+    t_joint = rt.timed(joint, K, W)
+    kmsR, kmsL = ringR.kernel_ms().mean(axis=0), ringL.kernel_ms().mean(axis=0)
     t_kr = rt.timed(lambda: senskernel.analytic_kernels(st["model"], per, wtype="R", nlay=st["nlay"]), K, W)
     t_kl = rt.timed(lambda: senskernel.analytic_kernels(st["model"], per, wtype="L", nlay=st["nlay"]), K, W)
     out = plan.run(st["model"], per, nlay=st["nlay"]); rt.barrier()
@@ -412,7 +485,13 @@ def workload_c5(rt, args, steps=None, warmup=None):
             "ms_thermal_parameters_to_stacks": t_gen / K * 1e3, "ms_joint_R_L_c_U": t_joint / K * 1e3,
             "ms_forward_plus_kernels_R": t_kr / K * 1e3, "ms_forward_plus_kernels_L": t_kl / K * 1e3,
             "kernel_sets_per_s_R": w * B * K / t_kr, "kernel_sets_per_s_L": w * B * K / t_kl,
-            "solved_fraction_R": okR, "solved_fraction_L": okL}
+            "solved_fraction_R": okR, "solved_fraction_L": okL,
+            "kernel_ms": {"rayleigh": {"prep": kmsR[0], "phase": kmsR[1], "group_and_finish": kmsR[2]},
+                          "love": {"prep": kmsL[0], "phase": kmsL[1], "group_and_finish": kmsL[2]},
+                          "how": "HIP events on each plan's own stream; the two streams share the chip, so a kernel's "
+                                 "duration includes the time it shares SIMDs with the other wave type's kernels"},
+            "roofline": leg_roofline("c5", kmsR[1], (20 * L + 8 * 20) * B),
+            "roofline_love_root_search": leg_roofline("c5", kmsL[1], (20 * L + 8 * 20) * B, kernel_prefix="surfdisp_phase_kernel<1,")}
 
 
 def main():
@@ -420,14 +499,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["all", "forward", "grid", "mcmc", "c5"], default="all",
+    ap.add_argument("--workload", choices=["all", "forward", "grid", "mcmc", "c5", "launchcheck"], default="all",
                     help="all (default): the forward headline line + short legs of the other BASELINE configs inside it; "
                          "a single name: only that workload, as the line itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: this process stays a plain launcher (no torch, no HIP); see launch_ranks
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     from pysurfinv_amd import _lib
     rt = Runtime(args)
+    if args.workload == "launchcheck":
+        # what every rank was handed by the launcher, gathered over the process group: proves the N > 1 entry without
+        # a solver call (tests/test_bench_launch.py runs it on CPU with BENCH_REHEARSAL=cpu)
+        mine = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        mine["pid"], mine["ppid"] = os.getpid(), os.getppid()
+        ranks = [mine]
+        if rt.dist is not None:
+            ranks = [None] * rt.world
+            rt.dist.all_gather_object(ranks, mine)
+        t, = rt.max_over_ranks(0.001 * (rt.rank + 1))
+        if rt.rank == 0:
+            print(json.dumps(rt.stamp({"metric": "launchcheck", "n_gpus": rt.world, "ranks": ranks, "max_over_ranks_check": t})), flush=True)
+        if rt.dist is not None:
+            rt.dist.barrier(); rt.dist.destroy_process_group()
+        return
     if _lib.lib().surfdisp_device_count() < 1:
         raise SystemExit("no HIP device: the product path has no CPU fallback")
 
@@ -451,7 +549,7 @@ def main():
             if line is not None:
                 line["workloads"] = extra
     if rt.rank == 0 and line is not None:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(rt.stamp(line)), flush=True)
     if rt.dist is not None:
         rt.dist.barrier()
         rt.dist.destroy_process_group()

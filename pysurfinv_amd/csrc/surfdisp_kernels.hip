@@ -735,6 +735,8 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     // shader cycles (s_memtime) of this wavefront: whole loop, evaluations of the secular function, stack rebuilds
     const unsigned long long wcyc0 = __builtin_readcyclecounter();
     unsigned long long wcyc_eval = 0, wcyc_build = 0, wcyc_pre = 0, wpasses = 0;
+    // team-passes by state, layers stepped per pass (the wavefront's trip count = max over lanes) and summed over lanes
+    unsigned long long wn_scan = 0, wn_refine = 0, wn_nevill = 0, wn_ellip = 0, wn_idle = 0, wtrip = 0, wlanelayers = 0, wlanes = 0;
 #endif
     const int lane = tid & 63;
     const int slot = tid / G;
@@ -959,6 +961,15 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         const unsigned long long we0 = __builtin_readcyclecounter();
         wcyc_pre += we0 - wp0;                                 // priority, trial velocities, layer dropping
         ++wpasses;
+        {
+            const unsigned long long lead = __ballot(j == 0);
+            wn_scan += __popcll(__ballot(st == ST_SCAN) & lead); wn_refine += __popcll(__ballot(st == ST_REFINE) & lead);
+            wn_nevill += __popcll(__ballot(st == ST_NEVILL) & lead); wn_ellip += __popcll(__ballot(st == ST_ELLIP) & lead);
+            wn_idle += __popcll(__ballot(st == ST_DONE) & lead);
+            int mx = eval ? mmj : 0, sm = eval ? mmj : 0;
+            for (int d = 32; d > 0; d >>= 1) { mx = max(mx, __shfl_xor(mx, d)); sm += __shfl_xor(sm, d); }
+            wtrip += mx; wlanelayers += sm; wlanes += __popcll(__ballot(eval));
+        }
 #endif
         if (eval) {
             if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, Lcap, S, mmj, cj, Tl, start)
@@ -1292,9 +1303,12 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
 #ifdef SD_WAVECLOCK
     if (!EXACT && A.wclk && (threadIdx.x & 63) == 0) {
         const size_t w = (size_t)blockIdx.x * (SD_PHASE_BLOCK / 64) + (threadIdx.x >> 6);
-        A.wclk[6 * w] = wclk0; A.wclk[6 * w + 1] = __builtin_amdgcn_s_memrealtime();
-        A.wclk[6 * w + 2] = __builtin_readcyclecounter() - wcyc0; A.wclk[6 * w + 3] = wcyc_eval;
-        A.wclk[6 * w + 4] = wcyc_build; A.wclk[6 * w + 5] = wpasses | (wcyc_pre << 20);
+        unsigned long long *o = A.wclk + 16 * w;
+        o[0] = wclk0; o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = __builtin_readcyclecounter() - wcyc0; o[3] = wcyc_eval;
+        o[4] = wcyc_build; o[5] = wpasses; o[6] = wcyc_pre;
+        o[7] = wn_scan; o[8] = wn_refine; o[9] = wn_nevill; o[10] = wn_ellip; o[11] = wn_idle;
+        o[12] = wtrip; o[13] = wlanelayers; o[14] = wlanes; o[15] = 0;
     }
 #endif
     if (INDEP) {

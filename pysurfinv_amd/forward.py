@@ -246,14 +246,15 @@ class JointPlan:
         self.s_ray = torch.cuda.Stream(device=self.device)
         self.s_love = torch.cuda.Stream(device=self.device)
 
-    def run(self, model, periods, nlay=None):
+    def run(self, model, periods, nlay=None, events=(None, None)):
+        """``events``: (Rayleigh, Love) ``EventRing`` slots, recorded on each plan's own stream (measurement)."""
         torch = self.torch
         cur = torch.cuda.current_stream(self.device)
         for s in (self.s_ray, self.s_love):
             s.wait_stream(cur)                       # inputs were produced on the caller's stream
         with torch.cuda.stream(self.s_ray):
-            cR, uR, sR = self.ray.run(model, periods, kind=_lib.KIND_RAYLEIGH, nlay=nlay, pipelined=True)
+            cR, uR, sR = self.ray.run(model, periods, kind=_lib.KIND_RAYLEIGH, nlay=nlay, pipelined=True, events=events[0])
         with torch.cuda.stream(self.s_love):
-            cL, uL, sL = self.love.run(model, periods, kind=_lib.KIND_LOVE, nlay=nlay, pipelined=True)
+            cL, uL, sL = self.love.run(model, periods, kind=_lib.KIND_LOVE, nlay=nlay, pipelined=True, events=events[1])
         cur.wait_stream(self.s_ray); cur.wait_stream(self.s_love)
         return dict(cR=cR, uR=uR, cL=cL, uL=uL, statusR=sR, statusL=sL)

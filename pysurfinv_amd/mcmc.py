@@ -67,6 +67,9 @@ class MetropolisBatch:
         # grid point of the reference's scan, so root selection and failures are the reference's on every input
         self.fast_scan = bool(fast_scan)
         self.n_forward = 0
+        # measurement hook (bench.py): a forward.EventRing whose next slot brackets the solver's kernels of each call
+        self.event_ring = None
+        self._ev_i = 0
 
     # ------------------------------------------------------------------ forward + misfit
     def forward_c(self, params):
@@ -80,8 +83,12 @@ class MetropolisBatch:
         C, _, L = model.shape
         if self._plan is None or (self._plan.B, self._plan.L) != (C, L):
             self._plan = BatchPlan(C, L, self.periods.numel(), device=self.device)
+        ev = None
+        if self.event_ring is not None:
+            ev = self.event_ring.slot(self._ev_i)
+            self._ev_i += 1
         c, _, st = self._plan.run(model.contiguous(), self.periods, kind=_lib.KIND_RAYLEIGH | _lib.PHASE_ONLY,
-                                  nlay=nlay, independent=self.independent, fast_scan=self.fast_scan)
+                                  nlay=nlay, independent=self.independent, fast_scan=self.fast_scan, events=ev)
         return c.to(torch.float64), st
 
     def misfit(self, params, rows=None, return_c=False):
@@ -119,6 +126,8 @@ class MetropolisBatch:
         """MCinv.perturb: redraw the WHOLE proposal while isgood() rejects it (models.py:192-205)."""
         torch = self.torch
         new = self.proposer.move(p)
+        if self.isgood is None:                                    # always good (models.py:220-224): no redraw loop,
+            return new                                             # and no host synchronisation in the lock step
         bad = ~self._good(new)
         tries = 1
         while tries < 1000 and bool(bad.any()):
@@ -133,6 +142,8 @@ class MetropolisBatch:
     def reset(self, C):
         """MCinv.reset: uniform prior draw, redrawn while isgood() rejects (models.py:206-219)."""
         new = self.proposer.reset(C)
+        if self.isgood is None:
+            return new
         bad = ~self._good(new)
         tries = 1
         while tries < 10000 and bool(bad.any()):

@@ -6,7 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-import bench
+from pysurfinv_amd import settings as bench
 from pysurfinv_amd import forward, _lib
 from pysurfinv_amd.layers_batch import Model1DBatch
 from pysurfinv_amd.brownian import TorchProposer

@@ -7,7 +7,7 @@
 
 ``--input``: npz with lons[n], lats[n], periods[P], c_obs[n, P], uncer[n, P] (NaN = masked period).
 ``--setting``: the reference's model setting as JSON (``models.py:42-51``; default: the continental example of
-``bench.py``).  Every rank inverts its block of points (``pysurfinv_amd.grid.run_grid``), writes
+``pysurfinv_amd.settings``).  Every rank inverts its block of points (``pysurfinv_amd.grid.run_grid``), writes
 ``{outdir}/{lon}_{lat}.npz`` with the reference's keys - what ``Model3D.loadInvDir`` (``model3D.py:36-57``) reads - and
 rank 0 writes ``{outdir}/summaries.npz``: one row per point of what ``PostPoint`` derives (minimum-misfit and average
 accepted model, misfits, predicted curve), gathered over RCCL.  ``--backend gloo --device cpu`` needs a ``forward``
@@ -37,7 +37,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import bench
+    from pysurfinv_amd import settings
     from pysurfinv_amd import grid
     from pysurfinv_amd.layers_batch import Model1DBatch
 
@@ -55,18 +55,15 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
-    setting = json.load(open(args.setting)) if args.setting else bench.MCMC_SETTING
+    setting = json.load(open(args.setting)) if args.setting else settings.MCMC_SETTING
     mb = Model1DBatch(setting, device=dev)
     if args.input:
         z = np.load(args.input)
         lons, lats, periods, c_obs, uncer = z["lons"], z["lats"], z["periods"], z["c_obs"], z["uncer"]
     else:
         n = max(1, args.synthetic)
-        class _RT:                                     # the synthetic observations of bench.py's grid leg
-            pass
-        rt = _RT(); rt.torch, rt.dev, rt.rank = torch, dev, 0
-        _, c_obs, uncer = bench._mcmc_setup(rt, n, args.chains)
-        periods = np.asarray(bench.MCMC_PERIODS, float)
+        _, c_obs, uncer = settings.synthetic_observations(n, dev)
+        periods = np.asarray(settings.MCMC_PERIODS, float)
         lons, lats = 230.0 + 0.5 * (np.arange(n) % 64), 40.0 + 0.5 * (np.arange(n) // 64)
     r = grid.run_grid(mb, lons, lats, periods, c_obs, uncer, args.chains, args.chainL, outdir=args.outdir,
                       rank=rank, world=world, device=str(dev), seed=args.seed, fast_scan=args.fast_scan, keep_tracks=False)
