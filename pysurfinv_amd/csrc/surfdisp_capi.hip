@@ -27,6 +27,7 @@ struct EnvKnobs {
     bool fastscan = false;        // SURFDISP_FASTSCAN=1: opt every call of the process into the heuristic scan
     int device = 0;               // SURFDISP_DEVICE (fast_surf_)
     int balance = -1;             // SURFDISP_BALANCE (developer knob): wavefront priority by progress, -1 = automatic
+    int rows_min_team = 8;        // SURFDISP_ROWS_MIN_TEAM (developer knob): teams of at least this many lanes rebuild from the row copy
     EnvKnobs()
     {
         if (const char *e = getenv("SURFDISP_TEAM")) team = atoi(e);
@@ -38,6 +39,7 @@ struct EnvKnobs {
         if (const char *e = getenv("SURFDISP_FASTSCAN")) fastscan = atoi(e) != 0;
         if (const char *e = getenv("SURFDISP_DEVICE")) device = atoi(e);
         if (const char *e = getenv("SURFDISP_BALANCE")) balance = atoi(e);
+        if (const char *e = getenv("SURFDISP_ROWS_MIN_TEAM")) rows_min_team = atoi(e);
     }
 };
 const EnvKnobs &knobs() { static const EnvKnobs k; return k; }
@@ -62,7 +64,7 @@ constexpr int SD_KIND_FLAGS = SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFD
 size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct Carve {
-    float *mdl, *ratio, *ct, *ut;
+    float *mdl, *rows, *ratio, *ct, *ut;
     int *nl, *nsolved;
     float *fsafe, *ovf;
     int *fb_count, *fb_list;
@@ -74,7 +76,8 @@ Carve carve(void *base, int B, int Lmax, int P)
     char *p = static_cast<char *>(base);
     size_t off = 0;
     Carve c;
-    c.mdl = reinterpret_cast<float *>(p + off);     off += align_up((size_t)9 * Lmax * B * sizeof(float));      // sd::NF staged fields
+    c.mdl = reinterpret_cast<float *>(p + off);     off += align_up((size_t)9 * Lmax * B * sizeof(float));      // sd::NF staged fields, SoA
+    c.rows = reinterpret_cast<float *>(p + off);    off += align_up((size_t)9 * Lmax * B * sizeof(float));      // ... and one row per stack and field
     c.ratio = reinterpret_cast<float *>(p + off);   off += align_up((size_t)P * B * sizeof(float));
     c.ct = reinterpret_cast<float *>(p + off);      off += align_up((size_t)P * B * sizeof(float));
     c.ut = reinterpret_cast<float *>(p + off);      off += align_up((size_t)P * B * sizeof(float));
@@ -238,7 +241,16 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     const long units = (indep ? (long)B * P : (long)B) * (pipelined ? 2 : 1);
     const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax, kind == SURFDISP_KIND_RAYLEIGH && !phase_only, pipelined);
 
-    sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl, P, indep ? w.nsolved : nullptr, w.fsafe, w.ovf, w.fb_count};
+    // Staged copy of the model the root search rebuilds its working stack from, once per period: with >= 8 lanes per
+    // stack consecutive lanes take consecutive layers, so the fields are laid out one row per stack (coalesced; from the
+    // SoA copy every value costs its own cache line: 12.5 GB of fabric traffic per 25 600 x 96-layer lock step,
+    // profiles/r03a).  Narrow teams read the SoA copy (consecutive stacks share a line).  The group-velocity kernel - one
+    // lane per (stack, period) - always reads the SoA copy; a phase-only call with rows skips writing it (the exact
+    // fallback launch reads whatever the production launch read).
+    const bool use_rows = (G >= kn.rows_min_team);
+    const bool need_soa = !use_rows || !phase_only;
+    sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl, P, indep ? w.nsolved : nullptr, w.fsafe, w.ovf, w.fb_count,
+                    use_rows ? w.rows : nullptr, need_soa ? 1 : 0};
     if (ev) SD_HIP(hipEventRecord(ev[0], s));
     SD_HIP(sd::launch_prep(s, kind, pa));
     if (ev) SD_HIP(hipEventRecord(ev[1], s));
@@ -249,6 +261,8 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
 #ifdef SD_WAVECLOCK
     ph.wclk = reinterpret_cast<unsigned long long *>(g_dbg.load(std::memory_order_relaxed));
 #endif
+    if (use_rows) { ph.msrc = w.rows; ph.ms_b = 9L * Lmax; ph.ms_f = Lmax; ph.ms_i = 1; }
+    else          { ph.msrc = w.mdl;  ph.ms_b = 1;         ph.ms_f = (long)Lmax * B; ph.ms_i = B; }
     SD_HIP(sd::launch_phase(s, kind, G, indep, ph));
     // the exact fallback re-solves what the production kernel listed (normally nothing: idle blocks exit at once)
     ph.overlap = 0; ph.fast = 0;

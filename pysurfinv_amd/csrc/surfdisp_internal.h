@@ -19,6 +19,10 @@ struct PrepArgs {
                           // 1e30 otherwise (the scan then skips nothing on that stack)
     float *ovf;           // [3][B]: thickest flattened layer, 2 ln(max rho), 4 ln(2 max Vs^2): entry_overflow_risk
     int *fb_count;        // [1]: zeroed here; stacks the production root search hands to the exact fallback
+    float *rows;          // nullptr, or [B][9][Lmax]: the same nine fields one ROW per stack and field - what the root
+                          // search's per-period rebuild reads when a stack has >= 8 lanes (consecutive lanes = consecutive
+                          // layers: coalesced; the SoA copy costs a cache line per value there)
+    int write_soa;        // 0: only the rows are needed (phase-only call with wide teams: no group-velocity kernel)
 };
 
 struct PhaseArgs {
@@ -41,6 +45,10 @@ struct PhaseArgs {
     int *fb_list;         // [teams]: team indices (stack, or period * B + stack in independent mode) for the exact kernel
     int balance;          // wavefront priority by progress (one batch in flight), see the kernel's main loop
     int strict;           // SURFDISP_STRICT: every team hands its stack to the exact kernel
+    // where the root search reads the staged fields: value (field f, layer i) of stack b at
+    // msrc[b * ms_b + f * ms_f + i * ms_i] - the SoA copy (1, Lmax * B, B) or the rows (9 * Lmax, Lmax, 1)
+    const float *msrc;
+    long ms_b, ms_f, ms_i;
 #ifdef SD_WAVECLOCK
     unsigned long long *wclk;   // developer build: [waves][2] s_memrealtime at wavefront start / end
 #endif

@@ -116,10 +116,11 @@ SD_HD inline void prep_stack(const PrepArgs &A, const int b)
             bmax = fmaxf(bmax, 1.06f * vs * fmaxf(dif, hsf));
             const size_t o = (size_t)i * B + b;
             const size_t fs = (size_t)Lmax * B;
-            mdl[F_VP * fs + o] = vp;   mdl[F_VS * fs + o] = vs;   mdl[F_RHO * fs + o] = rho;
-            mdl[F_QS * fs + o] = qs;
-            mdl[F_DIF * fs + o] = dif; mdl[F_QQQ * fs + o] = qqq; mdl[F_DFL * fs + o] = dfl;
-            mdl[F_HSF * fs + o] = hsf; mdl[F_HSR * fs + o] = hsr;
+            const float v9[NF] = {vp, vs, rho, qs, dif, qqq, dfl, hsf, hsr};      // F_VP .. F_HSR
+            for (int f = 0; f < NF; ++f) {
+                if (A.write_soa) mdl[f * fs + o] = v9[f];
+                if (A.rows) A.rows[((size_t)b * NF + f) * Lmax + i] = v9[f];
+            }
             r_i = r_n;
         }
     }
@@ -186,10 +187,12 @@ __global__ __launch_bounds__(256) void surfdisp_prep_kernel(PrepArgs A)
         rhomax = fmaxf(rhomax, rho * fmaxf(qqq, hsr));
         bmax = fmaxf(bmax, 1.06f * vs * fmaxf(dif, hsf));
         const size_t o = (size_t)i * B + b;
-        mdl[F_VP * fs + o] = vp;   mdl[F_VS * fs + o] = vs;   mdl[F_RHO * fs + o] = rho;
-        mdl[F_QS * fs + o] = qs;
-        mdl[F_DIF * fs + o] = dif; mdl[F_QQQ * fs + o] = qqq; mdl[F_DFL * fs + o] = dfl;
-        mdl[F_HSF * fs + o] = hsf; mdl[F_HSR * fs + o] = hsr;
+        const float v9[NF] = {vp, vs, rho, qs, dif, qqq, dfl, hsf, hsr};          // F_VP .. F_HSR
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            if (A.write_soa) mdl[f * fs + o] = v9[f];
+            if (A.rows) A.rows[((size_t)b * NF + f) * Lmax + i] = v9[f];          // consecutive lanes: consecutive words
+        }
     }
     // the stack's verdict and statistics over the lanes of its team
 #pragma unroll
@@ -256,10 +259,24 @@ SD_HD __forceinline__ LayerV layer_at(const float *__restrict__ mdl, size_t fs, 
 }
 
 // ================================================================ secular functions (registers)
-// LDS working stack of one team: w[(m*NFW + f)*S + slot], f = 0..5 (derived slot W_IR, b, rho, d, 1/a^2, 1/b^2):
+// LDS working stack of one team: w[m*LS + f*S + slot], f = 0..5 (derived slot W_IR, b, rho, d, 1/a^2, 1/b^2):
 // the six values of a layer sit at compile-time offsets f*S from one address (ds_read immediates)
 constexpr int NFW = 6;
-#define W_AT(m, f) wq[(((m) * NFW + (f)) * S)]
+// Layer stride LS (words) for S = SD_PHASE_BLOCK / G slots: NFW * S padded so that the lanes of a team - which take
+// consecutive LAYERS when they (re)build the stack, snapshot it or sum its thicknesses - fall into different LDS banks
+// together with the neighbouring teams of their 32-lane group.  NFW * S is a multiple of 32 words for every team size
+// up to 16 lanes: unpadded, all lanes of a team hit ONE bank (16-way conflicts on each of the 36 writes of a rebuild;
+// SQ_LDS_BANK_CONFLICT was 29-55 % of the LDS cycles, profiles/r03a).  Wanted: lane j, neighbouring slot t -> bank
+// (j * LS + t) mod 32 all different, i.e. LS = q * odd (mod 32) with q = 32 / G slots per group (1 for G >= 32).
+SD_HD constexpr int lds_ls(int S)
+{
+    const int G = SD_PHASE_BLOCK / S;
+    const int q = (G >= 32) ? 1 : 32 / G;
+    int ls = NFW * S;
+    while (ls % (2 * q) != q) ++ls;
+    return ls;
+}
+#define W_AT(m, f) wq[(m) * lds_ls(S) + (f) * S]
 #define W_IR(m) W_AT(m, 0)    // Rayleigh: layer 0 1/rho, layer m >= 1 rho(m-1)/rho(m) (rescale factor of the carried state); Love: 1/(rho b^2)
 #define W_B(m) W_AT(m, 1)
 #define W_R(m) W_AT(m, 2)
@@ -685,18 +702,19 @@ __device__ __noinline__ float delta_love_ref(const float *wq, const int Lcap, co
 __device__ __forceinline__ int drop_layers(const float *wq, const int Lcap, const int S,
                                            const int n, const float c, const float T)
 {
+    // mmax = ii + 1 at the first layer ii whose running sum exceeds dmax.  The thicknesses are >= 0, so the running sums
+    // never decrease and that layer is found by COUNTING the sums that do not exceed dmax: no "found" flag, no select
+    // per layer (five vector instructions per layer and none on the scalar unit; the flag version took six + five)
     const float dmax = FACT * c * T;
-    int mm = n;
+    int cnt = 0;
     float sum = 0.0f;
-    bool found = false;
-#pragma unroll 4
+#pragma unroll 8
     for (int ii = 0; ii < n; ++ii) {
         const float bi = W_B(ii), di = W_D(ii);
         sum = sum + ((c < bi) ? di : 0.0f);
-        const bool hit = (sum > dmax) && !found;
-        mm = hit ? ii + 1 : mm;
-        found = found || hit;
+        cnt += (sum > dmax) ? 0 : 1;
     }
+    const int mm = (cnt < n) ? cnt + 1 : n;
     return mm < 2 ? 2 : mm;
 }
 
@@ -760,11 +778,13 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     // kernel: a phase-only call (A.ratio == nullptr) skips it altogether
     const bool want_ratio = (KIND == 2) && (A.ratio != nullptr);
     const bool OVERLAP = !EXACT && want_ratio && (G >= 4) && !INDEP && (A.overlap != 0);
-    float *wq2 = w_lds + (size_t)NFW * Lcap * S + slot;
+    float *wq2 = w_lds + (size_t)lds_ls(S) * Lcap + slot;
     // NEVILL's interpolation table x(1..11), y(1..11) (surfa.f:8) of this team, behind the working stacks
-    float *nvx = w_lds + (size_t)((!EXACT && G >= 4 && A.overlap != 0) ? 2 : 1) * NFW * Lcap * S + (size_t)slot * 24, *nvy = nvx + 12;
-    const float *__restrict__ mdl = A.mdl;
-    const size_t fs = (size_t)Lcap * B;
+    float *nvx = w_lds + (size_t)((!EXACT && G >= 4 && A.overlap != 0) ? 2 : 1) * lds_ls(S) * Lcap + (size_t)slot * 24, *nvy = nvx + 12;
+    // staged fields of this team's stack (SoA copy or rows, see PhaseArgs): field f of layer i at M_AT(f, i)
+    const float *__restrict__ mrow = A.msrc + (size_t)b * A.ms_b;
+    const size_t msf = (size_t)A.ms_f, msi = (size_t)A.ms_i;
+#define M_AT(f, i) mrow[(size_t)(f) * msf + (size_t)(i) * msi]
 
     int n = 0, st = ST_DONE;
     if (team_valid) { n = A.nl[b]; if (n >= 2) st = ST_SCAN; }
@@ -812,13 +832,12 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             // this block runs whenever ANY team of the wavefront changes period, i.e. almost every
             // pass and with one or two teams active, so its loads and divisions are worth counting
             const bool hs = (i == nflat - 1);
-            const size_t o = (size_t)i * B + b;
             LayerRaw r;
-            r.a_ref = mdl[F_VP * fs + o]; r.b_ref = mdl[F_VS * fs + o]; r.rho_ref = mdl[F_RHO * fs + o];
-            r.qs = mdl[F_QS * fs + o];
-            r.dif = hs ? 0.0f : mdl[F_DIF * fs + o]; r.qqq = hs ? 0.0f : mdl[F_QQQ * fs + o];
-            r.dfl = hs ? 0.0f : mdl[F_DFL * fs + o];
-            r.hsf = hs ? mdl[F_HSF * fs + o] : 0.0f; r.hsr = hs ? mdl[F_HSR * fs + o] : 0.0f;
+            r.a_ref = M_AT(F_VP, i); r.b_ref = M_AT(F_VS, i); r.rho_ref = M_AT(F_RHO, i);
+            r.qs = M_AT(F_QS, i);
+            r.dif = hs ? 0.0f : M_AT(F_DIF, i); r.qqq = hs ? 0.0f : M_AT(F_QQQ, i);
+            r.dfl = hs ? 0.0f : M_AT(F_DFL, i);
+            r.hsf = hs ? M_AT(F_HSF, i) : 0.0f; r.hsr = hs ? M_AT(F_HSR, i) : 0.0f;
             const LayerV v = layer_derive(r, lnT, hs);
             // the reciprocals are this kernel's own helper values (not the reference's): v_rcp + one Newton
             // step (<= 1 ulp) instead of three IEEE divisions
@@ -875,10 +894,10 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         build(n);
         b1top = W_B(0);
         // first guess, fast_surf.f:157-171
-        const bool water = mdl[F_VS * fs + b] < 0.1f;
+        const bool water = M_AT(F_VS, 0) < 0.1f;
         const int il = water ? 1 : 0;
-        const float b_corr = mdl[F_QS * fs + (size_t)il * B + b] * logf(1.0f / T) / PI_REF;
-        float qq = mdl[F_VS * fs + (size_t)il * B + b];
+        const float b_corr = M_AT(F_QS, il) * logf(1.0f / T) / PI_REF;
+        float qq = M_AT(F_VS, il);
         if (KIND == 2) qq = 0.9f * qq;
         p0c = qq * (1.0f + b_corr);
         if (water) p0c = 0.5f;
@@ -1071,6 +1090,14 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         const int pl = (G > 1) ? lastl - 1 : lastl;            // lane before the last one
         const float pl_c = __shfl(cj, pl), pl_d = __shfl(val, pl);
         const int pl_mm = __shfl(mmj, pl);
+        // two lanes below / above the crossing lane and two before the last one: the fourth point of REFINE's
+        // second three-point estimate
+        const int lm2s = (src - 2 >= tbase) ? src - 2 : tbase;
+        const float e_ppc = __shfl(cj, lm2s), e_ppd = __shfl(val, lm2s);
+        const int nx2 = (src + 2 <= lastl) ? src + 2 : lastl;
+        const float e_n2c = __shfl(cj, nx2), e_n2d = __shfl(val, nx2);
+        const int pl2 = (G > 2) ? lastl - 2 : lastl;
+        const float pl2_c = __shfl(cj, pl2), pl2_d = __shfl(val, pl2);
         const bool had_ell = OVERLAP && ell_pend && (st == ST_SCAN);
 
         bool solved = false, failed = false;
@@ -1204,15 +1231,22 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             // new bracket + one more known point next to it (for the final 3-point step)
             float tc, td;
             bool tok = true;
+            float uc = 0.0f, ud = 0.0f;                        // a fourth point, on the other side where there is one
+            bool uok = false;
             const float oa = p0c, oda = p0d, ob = cb, odb = db;
+            const bool oaok = p0ok;
             if (fl >= 0) {
                 if (fl != tbase) p0ok = true;                  // low end replaced by a frozen-mmax point
                 p0c = e_pc; p0d = e_pd; cb = e_c; db = e_d;
                 if (fl < lastl) { tc = e_nc; td = e_nd; } else { tc = ob; td = odb; }
+                if (fl >= tbase + 2) { uc = e_ppc; ud = e_ppd; uok = true; }              // the point below the low end
+                else if (fl == tbase + 1) { uc = oa; ud = oda; uok = oaok; }              // ... which may be the old low end
+                else if (fl + 2 <= lastl) { uc = e_n2c; ud = e_n2d; uok = true; }         // first interval: two points above
+                else if (fl + 1 == lastl) { uc = ob; ud = odb; uok = true; }
             } else {
-                const bool oaok = p0ok;
                 p0c = l_c; p0d = l_d; p0ok = true;
                 if (G > 1) { tc = pl_c; td = pl_d; } else { tc = oa; td = oda; tok = oaok; }
+                if (G > 2) { uc = pl2_c; ud = pl2_d; uok = true; }
             }
             {
                 // Candidate root by inverse quadratic interpolation through the bracket ends and the
@@ -1230,7 +1264,17 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 if (!(ts <= w)) ts = w;
                 if (!p0ok) ts = 0.5f * w;                         // magnitudes not comparable: bisect
                 const bool inside = p0ok && tok && (t >= 0.0f) && (t <= w);
-                const bool agree = inside && (fabsf(t - ts) <= A.atol);
+                bool agree = inside && (fabsf(t - ts) <= A.atol);
+                if (inside && !agree && uok) {
+                    // The secant is only a second-order check: with a dozen evaluated points across the bracket a
+                    // SECOND three-point estimate (same bracket ends, the neighbour on the other side) is the sharper
+                    // witness - two cubically accurate estimates that agree to atol pin the root as well as another
+                    // pass of subdivision would (deep stacks: half of the periods took that extra pass for the
+                    // secant's sake, 28 of a stack's 95 passes instead of 19).
+                    const float sx2 = uc - p0c, f3 = ud;
+                    const float t2 = w * (f0 * f3) / ((f1 - f0) * (f1 - f3)) + sx2 * (f0 * f1) / ((f3 - f0) * (f3 - f1));
+                    agree = (t2 >= 0.0f) && (t2 <= w) && (fabsf(t - t2) <= A.atol);
+                }
                 ++passes;                                          // hard bound: fp32 cannot resolve <1 ulp
                 if (!(w > 1.0e-6f) || (!(w > A.wtol) && agree) || passes > 64) {
                     croot = p0c + (inside ? t : ts);
@@ -1243,7 +1287,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                                 for (int i = j; i < mm_frozen; i += G) {
 #pragma unroll
                                     for (int f = 0; f < NFW; ++f)
-                                        wq2[(i * NFW + f) * S] = wq[(i * NFW + f) * S];
+                                        wq2[i * lds_ls(S) + f * S] = wq[i * lds_ls(S) + f * S];
                                 }
                                 ell_pend = true; ell_k = k; ell_mm = mm_frozen; ell_c = croot; ell_T = T;
                                 solved = true;
@@ -1328,6 +1372,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         A.nsolved[b] = nsolved;
         if (A.status) A.status[b] = status;
     }
+#undef M_AT
 }
 
 template <int KIND, int G, bool INDEP, bool FAST = false, bool EXACT = false>
@@ -2114,9 +2159,9 @@ namespace sd {
 // working stack per team (+ the ellipticity snapshot slot for teams of >= 4 lanes; allocated for
 // Love too so that one number describes a launch)
 // NEVILL's table x(12), y(12) per team behind the working stack(s)
-size_t phase_lds_bytes(int Lmax, int G, bool overlap) { return (size_t)(((G >= 4 && overlap) ? 2 : 1) * NFW * Lmax + 24) * (SD_PHASE_BLOCK / G) * sizeof(float); }
+size_t phase_lds_bytes(int Lmax, int G, bool overlap) { const int S = SD_PHASE_BLOCK / G; return ((size_t)((G >= 4 && overlap) ? 2 : 1) * lds_ls(S) * Lmax + (size_t)24 * S) * sizeof(float); }
 // exact fallback: one working stack per team + NEVILL's table x(12), y(12)
-size_t phase_exact_lds_bytes(int Lmax, int G) { return (size_t)(NFW * Lmax + 24) * (SD_PHASE_BLOCK / G) * sizeof(float); }
+size_t phase_exact_lds_bytes(int Lmax, int G) { const int S = SD_PHASE_BLOCK / G; return ((size_t)lds_ls(S) * Lmax + (size_t)24 * S) * sizeof(float); }
 int phase_exact_team(int Lmax)
 {
     int G = 16;

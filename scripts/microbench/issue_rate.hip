@@ -59,7 +59,7 @@ int main(int argc, char **argv)
     hipMalloc(&out, (size_t)blocks * 256 * sizeof(float));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    const size_t lds = (size_t)NFW * L * 64 * sizeof(float);
+    const size_t lds = (size_t)lds_ls(64) * L * sizeof(float);
     for (int mode = 0; mode < 3; ++mode) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0, 0);

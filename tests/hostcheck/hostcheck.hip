@@ -13,6 +13,7 @@ extern "C" int sd_hostcheck_group(int B, int Lmax, const int *nlay, const float 
     std::vector<float> mdl((size_t)10 * Lmax * B);
     std::vector<int> nl(B);
     sd::PrepArgs pa{B, Lmax, nlay, model, mdl.data(), nl.data()};
+    pa.write_soa = 1;
     for (int b = 0; b < B; ++b) {
         if (kind == 2) sd::prep_stack<2>(pa, b); else sd::prep_stack<1>(pa, b);
     }
