@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SURFDISP_ABI_VERSION 2
+#define SURFDISP_ABI_VERSION 3
 #define SURFDISP_NPER_MAX 200      /* fast_surf.pyf:14-19: cvper and outputs are real*4[200] */
 #define SURFDISP_NLAY_MAX 200      /* layers per stack accepted by this library */
 
@@ -124,6 +124,16 @@ int surfdisp_forward_batch_device(void *stream, int B, int Lmax, const int *nlay
                                   const float *model, int P, const float *per, int kind,
                                   float *c, float *u, int *status,
                                   void *workspace, size_t workspace_bytes);
+
+/* ---- (3b) ABI 3: the same solve, which also returns the Rayleigh ELLIPTICITY the reference computes and keeps in
+ *          COMMON /o/ ratio(k, 1) (calcul.f:195: ratio = dltar(c1, t1, 3), i.e. DLTAR4 with mup = 2, surfa.f:360-363;
+ *          f2py exposes the block as a module attribute, fast_surf.pyf:126-140): ratio [B][P], 0 where unsolved.
+ *          `ratio` may be NULL (then identical to (3)); with SURFDISP_PHASE_ONLY the ellipticity recursions are still
+ *          run when `ratio` is given.  Love: zeros.  surfdisp_forward_batch_device stays for ABI 2 callers. */
+int surfdisp_forward_batch_device2(void *stream, int B, int Lmax, const int *nlay,
+                                   const float *model, int P, const float *per, int kind,
+                                   float *c, float *u, float *ratio, int *status,
+                                   void *workspace, size_t workspace_bytes);
 
 /* ---- (4) measurement variant of (3): identical launches bracketed by HIP events recorded on
  *          `stream`; blocks until done; kernel_ms[3] = durations of the prep, phase (root search)

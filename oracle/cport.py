@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libsurfdisp_oracle.so")
+# SURFDISP_ORACLE_LIB: another build of the same source (the sanitizer build of `make -C oracle asan`, scripts/sanitize_cpu.sh)
+_SO = os.environ.get("SURFDISP_ORACLE_LIB") or os.path.join(_HERE, "libsurfdisp_oracle.so")
 _lib = None
 
 OK, PARTIAL, NOROOT, NEVILL, EINVAL = 0, 1, 2, 3, -1
@@ -19,6 +20,8 @@ OK, PARTIAL, NOROOT, NEVILL, EINVAL = 0, 1, 2, 3, -1
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "surfdisp_oracle.c")
+    if os.environ.get("SURFDISP_ORACLE_LIB"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "libsurfdisp_oracle.so"],
                               stdout=subprocess.DEVNULL)

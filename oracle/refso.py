@@ -51,6 +51,16 @@ def _reset_state(L):
     ctypes.memset(dispe, 0, ctypes.sizeof(dispe))
 
 
+def last_ratio(nper):
+    """COMMON /o/ ratio(k, 1), k = 1..nper, as the last call left it: the Rayleigh ellipticity of every period
+    (calcul.f:195).  CALCUL is the routine that writes it and declares the block with nper = 2000 (calcul.f:5,7:
+    c(2000,20), t(2000), ratio(2000,20)) - fast_surf.f declares 200 - so the value of period k sits at float
+    2000 * 20 + 2000 + (k - 1) of the symbol ``o_``."""
+    o = (ctypes.c_float * (2000 * 20 + 2000 + 2000 * 20)).in_dll(lib(), "o_")
+    base = 2000 * 20 + 2000
+    return np.array([o[base + k] for k in range(int(nper))], np.float32)
+
+
 def fast_surf(nlay, ilvry, vp, vs, rho, h, qsinv, per, nper, fresh=True):
     """Reference fast_surf(): returns (ur0, ul0, cr0, cl0), float32[200] each."""
     L = lib()
@@ -75,15 +85,17 @@ def fast_surf(nlay, ilvry, vp, vs, rho, h, qsinv, per, nper, fresh=True):
     return tuple(outs)
 
 
-def forward_batch(vp, vs, rho, h, qsinv, periods, kind):
-    """Loop of reference calls over a [B, L] batch -> (c[B,P], u[B,P]) float32."""
+def forward_batch(vp, vs, rho, h, qsinv, periods, kind, want_ratio=False):
+    """Loop of reference calls over a [B, L] batch -> (c[B,P], u[B,P]) float32 (+ the ellipticities ratio[B,P])."""
     vp = np.asarray(vp); B, Ln = vp.shape
     P = len(periods)
-    c = np.zeros((B, P), np.float32); u = np.zeros((B, P), np.float32)
+    c = np.zeros((B, P), np.float32); u = np.zeros((B, P), np.float32); r = np.zeros((B, P), np.float32)
     for i in range(B):
         ur, ul, cr, cl = fast_surf(Ln, kind, vp[i], vs[i], rho[i], h[i], qsinv[i], periods, P)
         if kind == 2:
             c[i], u[i] = cr[:P], ur[:P]
         else:
             c[i], u[i] = cl[:P], ul[:P]
-    return c, u
+        if want_ratio:
+            r[i] = last_ratio(P)
+    return (c, u, r) if want_ratio else (c, u)

@@ -26,7 +26,7 @@ NPER_MAX, NLAY_MAX = 200, 200
 # every symbol include/surfdisp.h declares
 EXPORTS = (
     "fast_surf_", "surfdisp_forward_batch", "surfdisp_workspace_bytes",
-    "surfdisp_forward_batch_device", "surfdisp_forward_batch_device_timed",
+    "surfdisp_forward_batch_device", "surfdisp_forward_batch_device2", "surfdisp_forward_batch_device_timed",
     "surfdisp_forward_batch_device_events", "surfdisp_events_create", "surfdisp_events_destroy",
     "surfdisp_events_elapsed_ms", "surfdisp_params_to_model_device",
     "surfdisp_params_to_model_thermal_device", "surfdisp_thermal_scratch_bytes",
@@ -77,6 +77,10 @@ def lib() -> ctypes.CDLL:
     L.surfdisp_forward_batch_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp,
                                                 ctypes.c_int, vp, ctypes.c_int, vp, vp, vp,
                                                 vp, ctypes.c_size_t]
+    L.surfdisp_forward_batch_device2.restype = ctypes.c_int
+    L.surfdisp_forward_batch_device2.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp,
+                                                 ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp,
+                                                 vp, ctypes.c_size_t]
     L.surfdisp_forward_batch_device_timed.restype = ctypes.c_int
     L.surfdisp_forward_batch_device_timed.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp,
                                                       ctypes.c_int, vp, ctypes.c_int, vp, vp, vp,

@@ -217,7 +217,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
                                const float *model, int P, const float *per, int kind,
                                float *c, float *u, int *status,
                                void *workspace, size_t workspace_bytes, hipEvent_t *ev,
-                               float *kb = nullptr, float *ka = nullptr, float *kr = nullptr)
+                               float *kb = nullptr, float *ka = nullptr, float *kr = nullptr, float *ratio = nullptr)
 {
     int rc = check_args(B, Lmax, P, kind, model, per, c, u);
     if (rc) return rc;
@@ -235,11 +235,14 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     const bool strict = (kind & SURFDISP_STRICT) != 0;
     const bool fastscan = ((kind & SURFDISP_FASTSCAN) != 0 || kn.fastscan) && (kind & SURFDISP_EXACTSCAN) == 0 && !strict;
     kind &= ~SD_KIND_FLAGS;
+    // the ellipticity recursions (two more evaluations per period) feed the group-velocity kernel - and the caller who
+    // asked for the ratio itself (ABI 3), also in a phase-only call
+    const bool want_ell = (kind == SURFDISP_KIND_RAYLEIGH) && (!phase_only || ratio != nullptr);
     const Carve w = carve(workspace, B, Lmax, P);
     // independent mode has B*P root searches in flight: size the teams for that many; a caller that
     // keeps a second batch in flight (SURFDISP_PIPELINED) has twice the stacks on the chip
     const long units = (indep ? (long)B * P : (long)B) * (pipelined ? 2 : 1);
-    const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax, kind == SURFDISP_KIND_RAYLEIGH && !phase_only, pipelined);
+    const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax, want_ell, pipelined);
 
     // Staged copy of the model the root search rebuilds its working stack from, once per period: with >= 8 lanes per
     // stack consecutive lanes take consecutive layers, so the fields are laid out one row per stack (coalesced; from the
@@ -255,8 +258,8 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     SD_HIP(sd::launch_prep(s, kind, pa));
     if (ev) SD_HIP(hipEventRecord(ev[1], s));
     const float wtol = kn.refine_wtol, atol = kn.refine_atol, phimax = kn.phimax;
-    sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, phase_only ? nullptr : w.ratio, w.nsolved, status, wtol, atol,
-                     fastscan ? 1 : 0, w.fsafe, (kind == SURFDISP_KIND_RAYLEIGH && !phase_only && use_overlap(Lmax, G)) ? 1 : 0, phimax,
+    sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, want_ell ? w.ratio : nullptr, w.nsolved, status, wtol, atol,
+                     fastscan ? 1 : 0, w.fsafe, (want_ell && use_overlap(Lmax, G)) ? 1 : 0, phimax,
                      w.ovf, w.fb_count, w.fb_list, kn.balance >= 0 ? kn.balance : (pipelined ? 0 : 1), strict ? 1 : 0};
 #ifdef SD_WAVECLOCK
     ph.wclk = reinterpret_cast<unsigned long long *>(g_dbg.load(std::memory_order_relaxed));
@@ -285,8 +288,10 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
         if (ka) SD_HIP(sd::launch_kern_transpose(s, kscr + arr, ka, B, P, Lmax));
         if (kr) SD_HIP(sd::launch_kern_transpose(s, kscr + 2 * arr, kr, B, P, Lmax));
     }
+    if (ratio && kind != SURFDISP_KIND_RAYLEIGH) SD_HIP(hipMemsetAsync(ratio, 0, (size_t)B * P * sizeof(float), s));   // Love: zeros
     sd::FinishArgs fa{B, P, w.ct, phase_only ? nullptr : w.ut, c, phase_only ? nullptr : u,
-                      indep ? w.nsolved : nullptr, w.nl, status};
+                      indep ? w.nsolved : nullptr, w.nl, status,
+                      (ratio && want_ell) ? w.ratio : nullptr, (ratio && want_ell) ? ratio : nullptr, w.nsolved};
     SD_HIP(sd::launch_finish(s, fa));
     if (ev) SD_HIP(hipEventRecord(ev[3], s));
     return SURFDISP_SUCCESS;
@@ -299,6 +304,16 @@ int surfdisp_forward_batch_device(void *stream, int B, int Lmax, const int *nlay
 {
     return forward_device_impl(stream, B, Lmax, nlay, model, P, per, kind, c, u, status,
                                workspace, workspace_bytes, nullptr);
+}
+
+// ABI 3: the same solve, also returning the Rayleigh ellipticity the reference keeps in COMMON /o/ (calcul.f:195).
+int surfdisp_forward_batch_device2(void *stream, int B, int Lmax, const int *nlay,
+                                   const float *model, int P, const float *per, int kind,
+                                   float *c, float *u, float *ratio, int *status,
+                                   void *workspace, size_t workspace_bytes)
+{
+    return forward_device_impl(stream, B, Lmax, nlay, model, P, per, kind, c, u, status,
+                               workspace, workspace_bytes, nullptr, nullptr, nullptr, nullptr, ratio);
 }
 
 // Forward solve + analytic partial derivatives of the phase velocity with respect to each layer's

@@ -75,6 +75,9 @@ struct FinishArgs {
     const int *nsolved;   // nullptr (faithful) or [B] first failing period (independent mode)
     const int *nl;
     int *status;
+    const float *rt;      // nullptr, or [P][B] ellipticity (period-major, Rayleigh) ...
+    float *ratio;         // ... and the caller's [B][P] array it goes to (ABI 3)
+    const int *nsolved_all; // [B] periods solved (either mode): unsolved periods of `ratio` are written as 0
 };
 
 struct LayersArgs {

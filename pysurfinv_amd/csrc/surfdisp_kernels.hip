@@ -1169,7 +1169,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             }
         } else if (!EXACT && st == ST_REFINE && multi) {
             // more than one sign change inside the bracket: hand this period to NEVILL, from the scan's bracket
-            // (p0c, cb and their values are still the scan's: this is the first refine pass)
+            // (p0c, cb and their values are still the scan's: this is the first refine pass).  (Sending the whole stack
+            // to the exact fallback kernel instead changes nothing measurable: soak mismatch rates 1.70e-5 / 1.39e-5 ->
+            // 1.71e-5 / 1.36e-5, profiles/r03a/ab_multi_defer.txt.)
             nv_ic = 0; nv_nev = 1; nv_m = 1;
             croot = (p0c + cb) / 2.0f;
             st = ST_NEVILL;
@@ -1264,8 +1266,19 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 if (!(ts <= w)) ts = w;
                 if (!p0ok) ts = 0.5f * w;                         // magnitudes not comparable: bisect
                 const bool inside = p0ok && tok && (t >= 0.0f) && (t <= w);
-                bool agree = inside && (fabsf(t - ts) <= A.atol);
-                if (inside && !agree && uok) {
+                // Next to osculating modes the secular function bends sharply inside a bracket of a few 1e-4 km/s, and
+                // inverse interpolation - every three-point estimate alike - then misses the root by several 1e-6 while
+                // the estimates agree with each other (ragged fixture, 60 s: c off by 1.8e-6, which |dlnU/dlnc| = 560
+                // turns into 1e-3 of U).  Such a bracket is subdivided again: the slope towards a neighbouring point must
+                // be within a quarter of the slope across the bracket (ordinary brackets: a fraction of a percent).
+                auto bends = [&](float xs, float fs) {
+                    const float sm = (f1 - f0) / w;
+                    const float sn = (xs > w) ? (fs - f1) / (xs - w) : (f0 - fs) / (0.0f - xs);
+                    return !(fabsf(sn - sm) <= 0.25f * fabsf(sm));
+                };
+                const bool smooth = inside && !bends(sx, f2);
+                bool agree = smooth && (fabsf(t - ts) <= A.atol);
+                if (smooth && !agree && uok && !bends(uc - p0c, ud)) {
                     // The secant is only a second-order check: with a dozen evaluated points across the bracket a
                     // SECOND three-point estimate (same bracket ends, the neighbour on the other side) is the sharper
                     // witness - two cubically accurate estimates that agree to atol pin the root as well as another
@@ -2044,15 +2057,17 @@ __global__ __launch_bounds__(256) void surfdisp_finish_kernel(FinishArgs A)
                                      : (ns >= P ? SURFDISP_OK
                                      : (ns < 0 ? SURFDISP_NUMERIC : (ns == 0 ? SURFDISP_NOROOT : SURFDISP_PARTIAL)));
     }
-    for (int pass = 0; pass < 2; ++pass) {
-        const float *src = pass ? A.ut : A.ct;
-        float *dst = pass ? A.u : A.c;
+    for (int pass = 0; pass < 3; ++pass) {
+        const float *src = (pass == 0) ? A.ct : (pass == 1 ? A.ut : A.rt);
+        float *dst = (pass == 0) ? A.c : (pass == 1 ? A.u : A.ratio);
         if (!src || !dst) continue;                 // phase-only call: no group velocities (block-uniform)
         for (int i = threadIdx.x; i < 64 * P; i += 256) {
             const int k = i / 64, bl = i % 64;
             if (bl < nb) {
                 float v = src[(size_t)k * B + b0 + bl];
                 if (A.nsolved && k >= A.nsolved[b0 + bl]) v = 0.0f;   // independent mode: failure cascade
+                // the ellipticity slot of an unsolved period was never written
+                if (pass == 2 && (k >= A.nsolved_all[b0 + bl] || A.nl[b0 + bl] < 2)) v = 0.0f;
                 tile[bl * PS + k] = v;
             }
         }

@@ -5,7 +5,8 @@
 //
 // The host flattens the reference's `setting` into a descriptor:
 //   idesc: [0]=nlayers_in  [1]=ngrid  [2]=L(out)  [3]=has_ref  then per input layer (8 ints):
-//          kind, hslot, bottomdepth_flag, ncoef, grid_begin, grid_end, 0, 0 ; then coef slots
+//          kind, hslot, bottomdepth_flag, ncoef, grid_begin, grid_end, (first layer: slot + 1 of a per-row Info.topo,
+//          0 = the constant z_start), 0 ; then coef slots
 //          (nlayers_in x 8) ; then per output layer its top grid index (L ints)
 //   fdesc: [0]=z_start ; per input layer (1+8 doubles): hconst, coefconst[8] ;
 //          then per grid point (1+8 doubles): t in [0,1], basis row (vs = sum basis[k]*coef[k])
@@ -60,8 +61,10 @@ __global__ __launch_bounds__(256) void surfdisp_layers_kernel(LayersArgs A)
     const double *p = A.params + (size_t)c * A.N;
 
     // layer tops (a handful of layers): zbot[l] = z_start + sum of the thicknesses above
+    // A row of `params` is [random-walk parameters | per-point local constants] (Model1DBatch.set_local_info): both are
+    // read through slot indices.  Stack top z0 = -max(topo, 0), models.py:74.
     double ztop[10], Hl[10];
-    double z = A.fdesc[0];
+    double z = (lay_i[6] > 0) ? -fmax(p[lay_i[6] - 1], 0.0) : A.fdesc[0];
     for (int l = 0; l < nin; ++l) {
         const int hs = lay_i[8 * l + 1];
         double H = (hs >= 0) ? p[hs] : lay_f[9 * l];

@@ -10,8 +10,9 @@
 // lane of the wave - 61 unknowns - where the torch mirror uses cyclic reduction.
 //
 // Descriptor tail (after the arrays documented in surfdisp_layers.hip):
-//   idesc tail (8 ints): layer index, ThermAge slot, Tp slot, conversion (0 Ritzwoller, 1 Yamauchi),
-//                        Q age is constant (lithoAgeQ), bit mask of the crust layers above, npts, 0
+//   idesc tail (10 ints): layer index, ThermAge slot, Tp slot, conversion (0 Ritzwoller, 1 Yamauchi),
+//                        Q age is constant (lithoAgeQ), bit mask of the crust layers above, npts,
+//                        slot + 1 of a per-row Info.lithoAge, slot + 1 of a per-row Info.period (0 = the constants), 0
 //   fdesc tail (4 doubles): ThermAge const, Tp const, Q age const, Info.period
 #include <hip/hip_runtime.h>
 #include "surfdisp_internal.h"
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(64) void surfdisp_thermal_kernel(LayersArgs A)
     const int lh = hyb_i[0], npts = hyb_i[6];
 
     // thicknesses above the thermal layer (as in surfdisp_layers_kernel)
-    double z = A.fdesc[0], crust_h = 0.0, H = 0.0, z0 = 0.0;
+    double z = (lay_i[6] > 0) ? -fmax(p[lay_i[6] - 1], 0.0) : A.fdesc[0], crust_h = 0.0, H = 0.0, z0 = 0.0;
     for (int l = 0; l <= lh; ++l) {
         const int hs = lay_i[8 * l + 1];
         double Hl = (hs >= 0) ? p[hs] : lay_f[9 * l];
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(64) void surfdisp_thermal_kernel(LayersArgs A)
     const double age_p = hyb_i[1] >= 0 ? p[hyb_i[1]] : hyb_f[0];
     const double age = fmax(age_p, 1e-3);
     const double Tp = hyb_i[2] >= 0 ? p[hyb_i[2]] : hyb_f[1];
-    const double q_age = fmax(hyb_i[4] ? hyb_f[2] : age_p, 1e-3);
-    const double period = hyb_f[3];
+    const double q_age = fmax(hyb_i[4] ? (hyb_i[7] > 0 ? p[hyb_i[7] - 1] : hyb_f[2]) : age_p, 1e-3);
+    const double period = hyb_i[8] > 0 ? p[hyb_i[8] - 1] : hyb_f[3];
 
     const Tm2 m_vs = mantle_temperature(age, Tp);
     const Tm2 m_def = (Tp == 1325.0) ? m_vs : mantle_temperature(age, 1325.0);

@@ -104,7 +104,7 @@ class BatchPlan:
         return self.run(model, periods, kind=kind, nlay=nlay, _timed=True, independent=independent)
 
     def run(self, model, periods, kind=2, nlay=None, _timed=False, independent=False, events=None,
-            pipelined=False, fast_scan=False, strict=False):
+            pipelined=False, fast_scan=False, strict=False, want_ratio=False):
         """Launch the kernels on torch's current stream (no allocation, no sync).  ``events``: an
         ``EventRing`` slot (4 HIP events recorded on the launch stream around the kernels).
         ``pipelined``: the caller keeps a second batch in flight on another stream
@@ -139,11 +139,19 @@ class BatchPlan:
                 rc = _lib.lib().surfdisp_forward_batch_device_timed(*args, ms)
                 _lib.check(rc)
                 return self.c, self.u, self.status, tuple(float(x) for x in ms)
-            if events is not None:
+            if want_ratio:
+                # ABI 3: also the Rayleigh ellipticity (the reference's COMMON /o/ ratio, calcul.f:195) -> self.ratio [B, P]
+                if getattr(self, "ratio", None) is None:
+                    self.ratio = torch.zeros(self.B, self.P, dtype=torch.float32, device=self.device)
+                a2 = args[:10] + [ctypes.c_void_p(self.ratio.data_ptr())] + args[10:]
+                rc = _lib.lib().surfdisp_forward_batch_device2(*a2)
+            elif events is not None:
                 rc = _lib.lib().surfdisp_forward_batch_device_events(*args, events)
             else:
                 rc = _lib.lib().surfdisp_forward_batch_device(*args)
         _lib.check(rc)
+        if want_ratio:
+            return self.c, self.u, self.status, self.ratio
         return self.c, self.u, self.status
 
 

@@ -32,10 +32,14 @@ def summary_columns(n_params, n_periods):
 
 def run_grid(model_batch, lons, lats, periods, c_obs, uncer, chains_per_point, chainL, outdir=None,
              rank=0, world=1, device="cuda:0", seed=0, forward=None, isgood=None, fast_scan=False,
-             writer_threads=4, keep_tracks=True):
+             writer_threads=4, keep_tracks=True, local_info=None):
     """Invert the points owned by ``rank``.
 
-    model_batch : layers_batch.Model1DBatch (shared setting; per-point priors are the caller's job)
+    model_batch : layers_batch.Model1DBatch (one setting for the grid)
+    local_info  : None, or [n_points, K] - every point's own constants (``Point(setting, localInfo)``, point.py:8-14:
+                  ``Info.topo`` / ``lithoAge`` / ``period``, fixed thicknesses ...), columns = ``model_batch.aux_names``
+                  (the ``local_keys`` the model was built with).  The rank's block goes to the device once
+                  (``Model1DBatch.set_local_info``); every chain reads its point's row.
     c_obs, uncer: [n_points, P] (NaN / non-positive uncertainty = masked period)
     Returns dict(points=(lo, hi), mcTrack=[n_local, chains*chainL, 3+N] or None, summaries=[n_points, 6+2N+P]
     (every rank holds all rows, point order), columns, elapsed (sampling + summaries + gather, this rank),
@@ -54,11 +58,21 @@ def run_grid(model_batch, lons, lats, periods, c_obs, uncer, chains_per_point, c
     n_forward = 0
     tracks_dev = torch.zeros((n_local, chains_per_point * chainL, 3 + N), dtype=torch.float64, device=dev)
     summ = torch.zeros((n_local, 6 + 2 * N + P), dtype=torch.float64, device=dev)
+    if model_batch.n_aux and local_info is None:
+        raise ValueError(f"the model has per-point constants {model_batch.aux_names}: pass local_info[n_points, {model_batch.n_aux}]")
     if n_local > 0:
         # chain index = point-major: chains of one point are consecutive
         rep = lambda a: np.repeat(a[lo:hi], chains_per_point, axis=0)
+        local_rows = None
+        if local_info is not None:
+            li = np.asarray(local_info, float)
+            if li.shape != (n_points, model_batch.n_aux):
+                raise ValueError(f"local_info must be [{n_points}, {model_batch.n_aux}] (columns {model_batch.aux_names})")
+            model_batch.set_local_info(li[lo:hi])                        # this rank's points only
+            local_rows = np.repeat(np.arange(n_local), chains_per_point)
         mc = MetropolisBatch(model_batch.spec, model_batch.to_model, periods, rep(c_obs), rep(uncer),
-                             device=device, seed=seed + 7919 * rank, forward=forward, isgood=isgood, fast_scan=fast_scan)
+                             device=device, seed=seed + 7919 * rank, forward=forward, isgood=isgood, fast_scan=fast_scan,
+                             local_rows=local_rows)
         tracks_dev = mc.run_points(n_local, chains_per_point, chainL, on_device=True).reshape(n_local, chains_per_point * chainL, -1)
         first_chain = torch.arange(n_local, device=dev) * chains_per_point     # observation row of each point
         summ = mc.summarise_points(tracks_dev, first_chain)
@@ -76,7 +90,10 @@ def run_grid(model_batch, lons, lats, periods, c_obs, uncer, chains_per_point, c
         def write(i):
             pid = f"{lons[lo + i]}_{lats[lo + i]}"              # model3D.py:41-47 file naming
             obs = {"T": list(np.asarray(periods, float)), "c": list(c_obs[lo + i]), "uncer": list(uncer[lo + i])}
-            return MetropolisBatch.save_npz(outdir, pid, tracks[i], model_batch.setting, obs, chainL)
+            setting = model_batch.setting
+            if local_info is not None:                          # the point's own setting, as Point(setting, localInfo) keeps it
+                setting = model_batch.setting_for_row(np.asarray(local_info, float)[lo + i])
+            return MetropolisBatch.save_npz(outdir, pid, tracks[i], setting, obs, chainL)
         with ThreadPoolExecutor(max_workers=max(1, int(writer_threads))) as ex:
             list(ex.map(write, range(n_local)))
     elapsed_write = time.perf_counter() - t1

@@ -17,8 +17,18 @@ order, list elements in order.
 Supported layer types (rules cited per class): Sediment, Crust, Mantle/OceanMantle, OceanWater,
 OceanSediment, OceanCrust, OceanSedimentCascadia, the thermal OceanMantleHybrid (SURVEY.md 8f-4,
 ``layers.py:297-363`` over ``thermseis.py``), and the ReferenceMantle appended when ``Info.refLayer``
-is set (``models.py:116,153-154``).  The Crust ``Gauss`` option is out of scope (it needs the
-un-vendored ``Triforce.mathPlus.gaussFun``).
+is set (``models.py:116,153-154``).  The Crust ``Gauss`` option (``layers.py:176-183``) adds
+``A exp(-(z - mu)^2 / (2 sigma^2))`` to the B-spline profile: the reference takes the function from the un-vendored
+``Triforce.mathPlus.gaussFun(A, mu, sig, z)``, so the standard three-parameter form is assumed (pinned against the
+reference code path with that form standing in, ``tests/golden/make_golden_driver.py``).
+
+Per-point local information (``Point(setting, localInfo)``, ``point.py:8-14``; ``Model1D._loadLocalInfo``,
+``models.py:54-59``): a grid run has one ``Info.topo`` / ``lithoAge`` / ``period`` - and possibly one fixed thickness
+or velocity - PER POINT.  ``Model1DBatch(setting, local_keys=[...])`` declares which constants are per row
+(``'topo'``, ``'lithoAge'``, ``'period'``, or ``'<Layer>.<key>'`` / ``'<Layer>.Vs[i]'`` for a layer constant);
+``set_local_info(table[n_rows, K])`` puts the table on the device and every entry point takes ``rows`` (index of each
+parameter vector's table row).  The values travel as extra constant columns behind the random-walk parameters - no
+per-point Python objects, and the HIP kernels read them through the same slot indices.
 """
 from __future__ import annotations
 
@@ -92,11 +102,12 @@ def _n_fine_mantle(H):        # Crust / OceanMantle._nFineLayers, layers.py:156-
 
 
 class _Slot:
-    """A parameter value that is either a constant or column ``idx`` of the parameter block."""
-    __slots__ = ("const", "idx")
+    """A parameter value that is either a constant, or column ``idx`` of the parameter block (random-walk parameters
+    first, then the per-row local constants: ``aux`` = index among those, resolved to ``idx`` once N is known)."""
+    __slots__ = ("const", "idx", "aux")
 
-    def __init__(self, const=None, idx=None):
-        self.const, self.idx = const, idx
+    def __init__(self, const=None, idx=None, aux=None):
+        self.const, self.idx, self.aux = const, idx, aux
 
     def get(self, params):
         import torch
@@ -112,15 +123,31 @@ class Model1DBatch:
     GROUP = {"sed": "sediment", "osed": "sediment", "osedc": "sediment", "crust": "crust", "ocrust": "crust",
              "mantle": "mantle", "hybrid": "mantle", "water": "water"}
 
-    def __init__(self, setting: dict, device="cpu"):
+    def __init__(self, setting: dict, device="cpu", local_keys=None):
         import torch
         self.torch = torch
         self.device = torch.device(device)
         self.setting = setting
         self.info = dict(setting.get("Info", {}))
         entries, names = [], []
+        local_keys = list(local_keys or [])
+        if len(set(local_keys)) != len(local_keys):
+            raise ValueError("local_keys has duplicates")
+        # columns of the local-information table = local_keys, in the caller's order
+        self.aux_names, aux_slots, self._aux_default = list(local_keys), [], [None] * len(local_keys)
+        self._aux = None                                   # [n_rows, K] float64 on the device (set_local_info)
 
         def slot(v, name):
+            if name in local_keys:                         # a per-row constant (the setting's value = default)
+                if _is_brownian_entry(v):
+                    raise ValueError(f"{name}: a random-walk entry cannot be a per-point constant")
+                val = float(v[0]) if _is_fixed_entry(v) else float(v)
+                k = local_keys.index(name)
+                if self._aux_default[k] is not None:
+                    raise ValueError(f"{name} names more than one constant of the setting")
+                sl = _Slot(const=val, aux=k)
+                aux_slots.append(sl); self._aux_default[k] = val
+                return sl
             if _is_brownian_entry(v):
                 entries.append(list(v)); names.append(name)
                 return _Slot(idx=len(entries) - 1)
@@ -157,8 +184,11 @@ class Model1DBatch:
                     if v not in ("Ritzwoller", "Yamauchi"):
                         raise ValueError(f"Invalid convertion model: {v}")       # layers.py:338
                     lay[k] = v
-                elif k in ("Gauss",):
-                    raise ValueError("Crust 'Gauss' option is out of scope")
+                elif k == "Gauss" and kind == "crust":
+                    if v is not False and v is not None:   # layers.py:176: parm.get('Gauss', False) is False -> plain B-spline
+                        if not (isinstance(v, (list, tuple)) and len(v) == 3):
+                            raise ValueError("Crust 'Gauss' must be [A, mu, sigma]")
+                        lay["Gauss"] = [slot(e, f"{key}.Gauss[{i}]") for i, e in enumerate(v)]
                 elif _is_brownian_entry(v) or (isinstance(v, (list, tuple)) and any(_is_brownian_entry(e) for e in v)):
                     # the reference's _brownians() would count it (models.py:240-253): silently dropping it would
                     # shift every later mcTrack column against what PostPoint._loadMC expects
@@ -174,9 +204,75 @@ class Model1DBatch:
                 if runs != 1:                                  # getCrustH, layers.py:304-310
                     raise ValueError("OceanMantleHybrid: exactly one contiguous crust group must lie above it")
             self.layers.append(lay)
+        # Info constants a grid run has per point (models.py:74 topo; layers.py:350-363 lithoAge, period)
+        self._topo = slot(self.info.get("topo", 0.0), "topo")
+        self._litho = slot(self.info.get("lithoAge", 0.0) if self.info.get("lithoAge", None) is not None else 0.0, "lithoAge")
+        self._period = slot(self.info.get("period", 1), "period")
+        unknown = [k for k, d in zip(local_keys, self._aux_default) if d is None]
+        if unknown:
+            raise ValueError(f"local_keys {unknown} name no constant of this setting")
+        if "lithoAge" in self.aux_names and not self.info.get("lithoAgeQ", False):
+            raise ValueError("per-point lithoAge only acts with Info.lithoAgeQ (layers.py:353)")
         self.spec = ParamSpec.from_entries(entries, names)
+        for sl in aux_slots:                               # behind the random-walk parameters
+            sl.idx = self.spec.n + sl.aux
         self._basis = {}
         self._static_sig = self._find_static_signature()
+
+    # ------------------------------------------------------------------ per-point local information
+    @property
+    def n_aux(self):
+        return len(self.aux_names)
+
+    def set_local_info(self, table):
+        """``table`` [n_rows, K]: one row per point, columns in the order of ``aux_names`` (= ``local_keys``).  Kept on
+        the device; the fine-layer structure is re-examined over the prior box x the table's range."""
+        torch = self.torch
+        t = torch.as_tensor(np.asarray(table, dtype=np.float64), dtype=torch.float64, device=self.device)
+        if t.ndim != 2 or t.shape[1] != self.n_aux:
+            raise ValueError(f"local info must be [n_rows, {self.n_aux}] with columns {self.aux_names}")
+        self._aux = t.contiguous()
+        self._static_sig = self._find_static_signature()
+        self._native_desc = None
+        return self
+
+    def setting_for_row(self, values):
+        """The setting dict of ONE point: ``self.setting`` with the per-point constants ``values`` (order of
+        ``aux_names``) written back - what ``Point(setting, localInfo)`` would hold for it."""
+        import copy
+        import re
+        st = copy.deepcopy(self.setting)
+        for name, v in zip(self.aux_names, values):
+            v = float(v)
+            if "." not in name:
+                st.setdefault("Info", {})[name] = v
+                continue
+            layer, key = name.split(".", 1)
+            m = re.match(r"(\w+)\[(\d+)\]$", key)
+            if m:
+                st[layer][m.group(1)][int(m.group(2))] = v
+            else:
+                st[layer][key] = v
+        return st
+
+    def _full(self, params, rows=None):
+        """Parameter block + this row's local constants [B, N + K]."""
+        torch = self.torch
+        params = params.to(torch.float64)
+        if self.n_aux == 0:
+            return params
+        if self._aux is None:
+            raise ValueError(f"this model has per-point constants {self.aux_names}: call set_local_info(table) first")
+        if rows is None:
+            if params.shape[0] == 1 and self._aux.shape[0] >= 1:
+                aux = self._aux[:1]
+            elif params.shape[0] != self._aux.shape[0]:
+                raise ValueError(f"{params.shape[0]} parameter vectors against {self._aux.shape[0]} rows of local info: pass rows=")
+            else:
+                aux = self._aux
+        else:
+            aux = self._aux[torch.as_tensor(rows, device=self.device, dtype=torch.int64)]
+        return torch.cat([params, aux.to(params.device)], dim=1)
 
     def _find_static_signature(self):
         """Fine-layer counts are piecewise constant in the layer thickness.  If no thickness can cross
@@ -185,9 +281,15 @@ class Model1DBatch:
         import torch
         lo = torch.as_tensor(self.spec.vmin, dtype=torch.float64)[None, :]
         hi = torch.as_tensor(self.spec.vmax, dtype=torch.float64)[None, :]
-        topo = float(self.info.get("topo", 0.0))
-        zlo = torch.full((1,), -max(topo, 0.0), dtype=torch.float64)
-        zhi = zlo.clone()
+        if self.n_aux:
+            if self._aux is None:                          # no table yet: the setting's own values
+                a_lo = a_hi = torch.as_tensor(self._aux_default, dtype=torch.float64)[None, :]
+            else:
+                a_lo, a_hi = self._aux.min(dim=0).values.cpu()[None, :], self._aux.max(dim=0).values.cpu()[None, :]
+            lo, hi = torch.cat([lo, a_lo], dim=1), torch.cat([hi, a_hi], dim=1)
+        # stack top z0 = -max(topo, 0) (models.py:74): deepest for the largest topo
+        zlo = -self._topo.get(hi).clamp(min=0.0)
+        zhi = -self._topo.get(lo).clamp(min=0.0)
         sig = []
         for lay in self.layers:
             h_lo, h_hi = lay["H"].get(lo), lay["H"].get(hi)
@@ -247,12 +349,13 @@ class Model1DBatch:
         lay["zmelt_last"] = z_melt                      # the reference keeps it too (_debug_zMelt)
         lay["grid_last"] = None
         # _calOthers, layers.py:350-363
-        if self.info.get("lithoAgeQ", False) and self.info.get("lithoAge", None) is not None:
-            q_age = torch.full_like(age, float(self.info["lithoAge"]))
+        if self.info.get("lithoAgeQ", False) and (self.info.get("lithoAge", None) is not None or self._litho.aux is not None):
+            q_age = self._litho.get(params)
         else:
             q_age = age_p
         ther_q = ts.hscm(q_age.clamp(min=1e-3), zdeps=z_bottom[:, None] + z)
-        qs = ts.ruan(ther_q, period=float(self.info.get("period", 1)))[1].clamp(max=5000.0)
+        period = self._period.get(params)[:, None] if self._period.aux is not None else float(self.info.get("period", 1))
+        qs = ts.ruan(ther_q, period=period)[1].clamp(max=5000.0)
         lay["grid_last"] = (vs, qs)
         return z, vs, vs * 1.76, 3.4268 + (vs - 4.5) / 4.5, qs, 1400. * torch.ones_like(vs)
 
@@ -283,6 +386,9 @@ class Model1DBatch:
             vs = coef[:, :1] * ones
         else:                                              # B-spline layers, layers.py:169-172, 258-261
             vs = coef @ self._bspl(N, nb, lay.get("deg"))
+            if kind == "crust" and "Gauss" in lay:             # layers.py:176-183: + gaussFun(A, mu, sig, z)
+                ga, gm, gs = (sl.get(params)[:, None] for sl in lay["Gauss"])
+                vs = vs + ga * torch.exp(-((z - gm) ** 2) / (2.0 * gs * gs))
         if kind == "sed":                                  # layers.py:150-155
             vp = vs * 2.0
             rho = 1.22679 + 1.53201 * vs - 0.83668 * vs * vs + 0.20673 * vs ** 3 - 0.01656 * vs ** 4
@@ -322,22 +428,22 @@ class Model1DBatch:
         return torch.where(H < H_LOWER, torch.full_like(N, -1), N), H     # -1: layer skipped (models.py:80-81)
 
     # ------------------------------------------------------------------ public
-    def seis_prop_layers(self, params):
+    def seis_prop_layers(self, params, rows=None):
         """(h, vs, vp, rho, qs, qp) float64 [B, Lmax] padded with zeros, and nlay[B] -
-        ``Model1D.seisPropLayers(refLayer=Info.refLayer)`` for every row of ``params``."""
+        ``Model1D.seisPropLayers(refLayer=Info.refLayer)`` for every row of ``params`` (``rows``: the local-info row of
+        each parameter vector, see ``set_local_info``)."""
         torch = self.torch
-        params = params.to(torch.float64)
+        params = self._full(params, rows)
         B = params.shape[0]
         ref_layer = bool(self.info.get("refLayer", False))
-        topo = float(self.info.get("topo", 0.0))
-        z_start = -max(topo, 0.0)                          # models.py:75
+        z_start = -self._topo.get(params).clamp(min=0.0)   # models.py:74, per row
         # pass 1: fine-layer counts (they depend on the thicknesses, hence on the parameters)
         static = self._static_sig is not None
         if static:
             uniq = torch.as_tensor([self._static_sig], dtype=torch.int64)
             inv = None
         else:
-            zb = torch.full((B,), z_start, dtype=torch.float64, device=self.device)
+            zb = z_start.clone()
             sig = []
             for lay in self.layers:
                 N, H = self._n_fine(lay, params, zb)
@@ -350,10 +456,10 @@ class Model1DBatch:
         out = [torch.zeros((B, Lcap), dtype=torch.float64, device=self.device) for _ in range(6)]
         nlay = torch.zeros(B, dtype=torch.int32, device=self.device)
         for g in range(uniq.shape[0]):
-            rows = slice(None) if static else (inv == g).nonzero(as_tuple=True)[0]
+            rows = slice(None) if static else (inv == g).nonzero(as_tuple=True)[0]     # (shadows the argument: consumed above)
             p = params[rows]
             nrows = p.shape[0]
-            zbot = torch.full((nrows,), z_start, dtype=torch.float64, device=self.device)
+            zbot = z_start[rows].clone()
             cols = [[] for _ in range(6)]
             crust_h = torch.zeros_like(zbot)
             for li, lay in enumerate(self.layers):
@@ -400,7 +506,9 @@ class Model1DBatch:
     def native_descriptor(self):
         """(idesc int32, fdesc float64, L) for csrc/surfdisp_layers.hip, or None when the layer
         structure is not static.  Cached on the model's device."""
-        if self._static_sig is None or len(self.layers) > 10:
+        if self._static_sig is None or len(self.layers) > 10 or any("Gauss" in lay for lay in self.layers):
+            return None                                    # (the Gaussian crust term is evaluated by the torch path)
+        if self.n_aux and self._aux is None:
             return None
         hybrids = [i for i, lay in enumerate(self.layers) if lay["kind"] == "hybrid"]
         if len(hybrids) > 1 or (hybrids and self._static_sig[hybrids[0]] + 1 > 64):
@@ -420,8 +528,10 @@ class Model1DBatch:
             if len(slots) > 8:
                 return None
             begin, end = g, g + N + 1
+            # int 6 of the FIRST layer: slot + 1 of a per-row Info.topo (0: the constant z_start of fdesc[0])
+            topo_ref = (self._topo.idx + 1) if (not lay_i and self._topo.idx is not None) else 0
             lay_i += [self.KIND_CODE[lay["kind"]], hs.idx if hs.idx is not None else -1,
-                      1 if lay.get("Hkey") == "BottomDepth" else 0, len(slots), begin, end, 0, 0]
+                      1 if lay.get("Hkey") == "BottomDepth" else 0, len(slots), begin, end, topo_ref, 0]
             coef_i += [(sl.idx if sl.idx is not None else -1) for sl in slots] + [-1] * (8 - len(slots))
             lay_f += [float(hs.const) if hs.const is not None else 0.0]
             lay_f += [(float(sl.const) if sl.const is not None else 0.0) for sl in slots] + [0.0] * (8 - len(slots))
@@ -449,26 +559,30 @@ class Model1DBatch:
             tops += list(range(ngrid, ngrid + 20))
         L = len(tops)
         idesc = [nin, ngrid, L, 1 if ref else 0] + lay_i + coef_i + tops
-        topo = float(self.info.get("topo", 0.0))
+        topo = float(self._topo.const if self._topo.const is not None else 0.0)
         fdesc = [-max(topo, 0.0)] + lay_f + grid_f
         self._native_thermal = bool(hybrids)
         if hybrids:                                        # descriptor tail, csrc/surfdisp_thermal.hip
             lh = hybrids[0]
             lay = self.layers[lh]
             age, tp = lay["ThermAge"], lay.get("Tp", _Slot(const=1325.0))
-            q_const = bool(self.info.get("lithoAgeQ", False)) and self.info.get("lithoAge", None) is not None
+            q_const = bool(self.info.get("lithoAgeQ", False)) and (self.info.get("lithoAge", None) is not None
+                                                                   or self._litho.aux is not None)
             crust_mask = sum(1 << i for i, l in enumerate(self.layers[:lh]) if self.GROUP[l["kind"]] == "crust")
+            # ints 7, 8: slot + 1 of a per-row Info.lithoAge / Info.period (0: the constants of the fdesc tail)
             idesc += [lh, age.idx if age.idx is not None else -1, tp.idx if tp.idx is not None else -1,
                       1 if lay.get("Conversion", "Ritzwoller") == "Yamauchi" else 0, 1 if q_const else 0,
-                      crust_mask, self._static_sig[lh] + 1, 0]
+                      crust_mask, self._static_sig[lh] + 1,
+                      (self._litho.idx + 1) if self._litho.idx is not None else 0,
+                      (self._period.idx + 1) if self._period.idx is not None else 0, 0]
             fdesc += [float(age.const) if age.const is not None else 0.0,
                       float(tp.const) if tp.const is not None else 0.0,
-                      float(self.info["lithoAge"]) if q_const else 0.0, float(self.info.get("period", 1))]
+                      float(self._litho.const) if q_const else 0.0, float(self._period.const)]
         self._native_desc = (torch.tensor(idesc, dtype=torch.int32, device=self.device),
                              torch.tensor(fdesc, dtype=torch.float64, device=self.device), L)
         return self._native_desc
 
-    def to_model_native(self, params):
+    def to_model_native(self, params, rows=None):
         """``to_model`` through the HIP kernel surfdisp_layers_kernel (one launch, graph-capturable)."""
         import ctypes
         from . import _lib
@@ -477,7 +591,7 @@ class Model1DBatch:
         if desc is None or params.device.type != "cuda":
             raise _lib.SurfdispError("native parameters->stack needs a static layer structure and a HIP device")
         idesc, fdesc, L = desc
-        p = params.to(torch.float64).contiguous()
+        p = self._full(params, rows).contiguous()          # [C, N + K]: the kernels index the local constants like parameters
         C, N = p.shape
         model = torch.empty((C, 5, L), dtype=torch.float32, device=p.device)
         stream = torch.cuda.current_stream(p.device).cuda_stream
@@ -497,15 +611,16 @@ class Model1DBatch:
         _lib.check(rc)
         return model, None
 
-    def to_model(self, params):
+    def to_model(self, params, rows=None):
         """model float32 [B, 5, Lmax] rows (vp, vs, rho, h, 1/Qs) + nlay - what ``_calForward``
         hands to ``fast_surf`` (models.py:20-27).  On a HIP device with a static layer structure this
-        is one kernel launch (``to_model_native``); otherwise the torch implementation below."""
+        is one kernel launch (``to_model_native``); otherwise the torch implementation below.  ``rows``: the local-info
+        row of each parameter vector (models with per-point constants, ``set_local_info``)."""
         if params.device.type == "cuda" and self.native_descriptor() is not None:
-            return self.to_model_native(params)
-        return self.to_model_torch(params)
+            return self.to_model_native(params, rows)
+        return self.to_model_torch(params, rows)
 
-    def forward(self, params=None, periods=(5, 10, 20, 40, 60, 80), wavetype="Ray"):
+    def forward(self, params=None, periods=(5, 10, 20, 40, 60, 80), wavetype="Ray", rows=None):
         """``Model1D.forward(periods)`` (models.py:116-122) for every row of ``params`` (default: the
         setting's own values): phase velocities float32 [B, P] through the HIP solver, rows of zeros where
         the reference would return ``None``; status [B]."""
@@ -516,16 +631,16 @@ class Model1DBatch:
             raise _lib.SurfdispError("Model1DBatch.forward needs a HIP device (no CPU fallback)")
         if params is None:
             params = torch.as_tensor(self.spec.v0[None, :], dtype=torch.float64, device=self.device)
-        model, nlay = self.to_model(params)
+        model, nlay = self.to_model(params, rows)
         per = torch.as_tensor(_np.asarray(periods, _np.float32), device=self.device)
         kind = {"Ray": _lib.KIND_RAYLEIGH, "Love": _lib.KIND_LOVE}[wavetype] | _lib.PHASE_ONLY
         plan = _fw.BatchPlan(model.shape[0], model.shape[2], per.numel(), device=self.device)
         c, _, st = plan.run(model.contiguous(), per, kind=kind, nlay=nlay)
         return c, st
 
-    def to_model_torch(self, params):
+    def to_model_torch(self, params, rows=None):
         torch = self.torch
-        (h, vs, vp, rho, qs, qp), nlay = self.seis_prop_layers(params)
+        (h, vs, vp, rho, qs, qp), nlay = self.seis_prop_layers(params, rows)
         qsinv = torch.where(qs > 0, 1.0 / torch.where(qs > 0, qs, torch.ones_like(qs)), torch.zeros_like(qs))
         model = torch.stack([vp, vs, rho, h, qsinv], dim=1).to(torch.float32).contiguous()
         return model, nlay

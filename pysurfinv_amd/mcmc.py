@@ -44,7 +44,8 @@ class MetropolisBatch:
     """
 
     def __init__(self, spec: ParamSpec, to_model, periods, c_obs, uncer, device="cuda:0",
-                 isgood=None, proposer=None, seed=None, forward=None, independent=False, fast_scan=False):
+                 isgood=None, proposer=None, seed=None, forward=None, independent=False, fast_scan=False,
+                 local_rows=None):
         import torch
         self.torch = torch
         self.device = torch.device(device)
@@ -67,15 +68,25 @@ class MetropolisBatch:
         # grid point of the reference's scan, so root selection and failures are the reference's on every input
         self.fast_scan = bool(fast_scan)
         self.n_forward = 0
+        # local_rows [C]: row of the model's per-point local-information table (Model1DBatch.set_local_info) each chain
+        # belongs to; to_model is then called as to_model(params, rows)
+        self.local_rows = None if local_rows is None else torch.as_tensor(np.asarray(local_rows), dtype=torch.int64,
+                                                                          device=self.device)
         # measurement hook (bench.py): a forward.EventRing whose next slot brackets the solver's kernels of each call
         self.event_ring = None
         self._ev_i = 0
 
     # ------------------------------------------------------------------ forward + misfit
-    def forward_c(self, params):
-        """Rayleigh phase velocities c[C, P] and status[C] for the stacks of ``params``."""
+    def forward_c(self, params, rows=None):
+        """Rayleigh phase velocities c[C, P] and status[C] for the stacks of ``params`` (``rows``: the chain each row
+        of ``params`` belongs to, when it is not simply row i = chain i)."""
         torch = self.torch
-        model, nlay = self.to_model(params)
+        if self.local_rows is not None:
+            if rows is None and params.shape[0] != self.local_rows.shape[0]:
+                raise ValueError(f"{params.shape[0]} models against {self.local_rows.shape[0]} chains with local information: pass rows=")
+            model, nlay = self.to_model(params, self.local_rows if rows is None else self.local_rows[rows])
+        else:
+            model, nlay = self.to_model(params)
         self.n_forward += model.shape[0]
         if self._forward is not None:
             return self._forward(model, nlay)
@@ -97,7 +108,7 @@ class MetropolisBatch:
         index tensor) is given - the speculative sampler evaluates several proposals per chain, the grid driver
         one average model per point."""
         torch = self.torch
-        cP, st = self.forward_c(params)
+        cP, st = self.forward_c(params, rows)
         failed = (st != 0) | (cP < 0.01).any(dim=1)            # models.py:29-33
         c_obs, uncer, mask = self.c_obs, self.uncer, self.mask
         if c_obs.ndim == 2:
@@ -248,7 +259,7 @@ class MetropolisBatch:
                 S[:, 2 * ks + 1] = q
                 S[:, 2 * ks + 2] = S[:, lo:hi]
             # ONE forward solve of C*M stacks; proposal m of chain i is held against chain i's observations
-            misQ, chiQ, LQ = self.misfit(Q.reshape(-1, N), rows=ar.repeat_interleave(M) if self.c_obs.ndim == 2 else None)
+            misQ, chiQ, LQ = self.misfit(Q.reshape(-1, N), rows=ar.repeat_interleave(M) if (self.c_obs.ndim == 2 or self.local_rows is not None) else None)
             misQ, chiQ, LQ = misQ.reshape(C, M), chiQ.reshape(C, M), LQ.reshape(C, M)
             node = torch.zeros(C, dtype=torch.int64, device=self.device)
             for _ in range(min(d, chainL - i)):

@@ -40,7 +40,10 @@ def install(reference_root="/root/reference"):
     mod("Triforce").__path__ = []
     mod("Triforce.pltHead", plt=Dummy(), mpl=Dummy(), np=np)
     mod("Triforce.obspyPlus", randString=lambda n: "X" * n)
-    mod("Triforce.mathPlus", logQuad=Dummy(), gaussFun=Dummy())
+    # gaussFun(A, mu, sig, x): un-vendored; the standard three-parameter Gaussian stands in (the form
+    # pysurfinv_amd.layers_batch assumes for the Crust 'Gauss' option, layers.py:176-183) - parity of that one
+    # function's exact form is unpinned, the code path around it is the reference's
+    mod("Triforce.mathPlus", logQuad=Dummy(), gaussFun=lambda A, mu, sig, x: A * np.exp(-(np.asarray(x) - mu) ** 2 / (2.0 * sig ** 2)))
     mod("Triforce.utils", GeoGrid=Dummy(), GeoMap=Dummy())
     mod("Triforce.customPlot", addAxes=Dummy(), addCAxes=Dummy())
     mod("netCDF4", Dataset=Dummy())

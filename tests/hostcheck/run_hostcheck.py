@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_cases
 from oracle import cport
 
-H = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhostcheck.so"))
+H = ctypes.CDLL(os.environ.get("SURFDISP_HOSTCHECK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhostcheck.so"))
 O = cport.lib()
 fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
 

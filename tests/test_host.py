@@ -17,11 +17,11 @@ def test_library_loads_and_exports_every_declared_symbol():
     L = _lib.lib()
     hdr = open(os.path.join(ROOT, "include", "surfdisp.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(surfdisp_[a-z_]+|fast_surf_)\s*\(", hdr))
+    declared = set(re.findall(r"\b(surfdisp_[a-z0-9_]+|fast_surf_)\s*\(", hdr))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.surfdisp_abi_version() == 2
+    assert L.surfdisp_abi_version() == 3
     assert L.surfdisp_kernel_name(1) == b"surfdisp_phase_kernel"
 
 

@@ -21,6 +21,10 @@ def hostlib():
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
     so = os.path.join(HC, "libhostcheck.so")
+    if os.environ.get("SURFDISP_HOSTCHECK_LIB"):               # sanitizer build (scripts/sanitize_cpu.sh): use as is
+        sys.path.insert(0, HC)
+        import run_hostcheck
+        return run_hostcheck
     src = [os.path.join(HC, "hostcheck.hip"), os.path.join(HERE, "..", "pysurfinv_amd", "csrc", "surfdisp_kernels.hip")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in src):
         subprocess.check_call([HIPCC, "-O2", "-std=c++17", "--offload-arch=gfx950", "-fPIC",
