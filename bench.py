@@ -433,6 +433,14 @@ def workload_mcmc(rt, args, steps=None, warmup=None):
     out.update({"value": rt.world * 100 * K / dt, "ms_per_lock_step": dt / K * 1e3, "steps": K, "scaling": "weak",
                 "kernel_ms": {"prep": kms[0], "phase": kms[1], "finish": kms[2]},
                 "roofline": leg_roofline("mcmc", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * 100)})
+    # the same lock step with the opt-in (stack, period) decomposition for small chain counts (independent="auto")
+    mca = MetropolisBatch(mb.spec, mb.to_model, MCMC_PERIODS, c_obs[0], unc[0], device=rt.dev, seed=3 + rt.rank, independent="auto")
+    mca.run(100, 4); rt.barrier()
+    t0 = time.perf_counter(); mca.run(100, K + 1); rt.barrier()
+    dta, = rt.max_over_ranks(time.perf_counter() - t0)
+    out.update({"value_independent_auto": rt.world * 100 * K / dta, "ms_per_lock_step_independent_auto": dta / K * 1e3,
+                "independent_auto_note": "opt-in: MetropolisBatch(independent='auto') / Point.MCinvMP(independent='auto'); "
+                                         "equal to the faithful walk to 4e-6 on this model (scripts/indep_vs_faithful.py)"})
     try:
         mc.run_graphed(100, 8); rt.barrier()
         t0 = time.perf_counter(); mc.run_graphed(100, 4 * K + 2); rt.barrier()

@@ -154,6 +154,9 @@ int surfdisp_forward_batch_device_events(void *stream, int B, int Lmax, const in
 int surfdisp_events_create(int n, void **events);
 int surfdisp_events_destroy(int n, void **events);
 int surfdisp_events_elapsed_ms(void *start, void *stop, float *ms);
+/*          surfdisp_stream_wait_event: `stream` waits for one of those events (recorded on another stream) - a caller with two
+ *          solves on two streams orders their kernels with it (pysurfinv_amd.forward.JointPlan). */
+int surfdisp_stream_wait_event(void *stream, void *event);
 
 /* ---- (5b) forward solve + analytic sensitivity kernels.  REIGEN / LEIGEN form the
  *          partial derivatives of the phase velocity from their energy integrals and never return

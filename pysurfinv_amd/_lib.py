@@ -28,7 +28,7 @@ EXPORTS = (
     "fast_surf_", "surfdisp_forward_batch", "surfdisp_workspace_bytes",
     "surfdisp_forward_batch_device", "surfdisp_forward_batch_device2", "surfdisp_forward_batch_device_timed",
     "surfdisp_forward_batch_device_events", "surfdisp_events_create", "surfdisp_events_destroy",
-    "surfdisp_events_elapsed_ms", "surfdisp_params_to_model_device",
+    "surfdisp_events_elapsed_ms", "surfdisp_stream_wait_event", "surfdisp_params_to_model_device",
     "surfdisp_params_to_model_thermal_device", "surfdisp_thermal_scratch_bytes",
     "surfdisp_forward_kernels_device", "surfdisp_kernels_workspace_bytes", "surfdisp_workspace_fallback_count", "surfdisp_set_team", "surfdisp_get_team",
     "surfdisp_device_count", "surfdisp_abi_version", "surfdisp_last_error",
@@ -93,6 +93,8 @@ def lib() -> ctypes.CDLL:
     L.surfdisp_events_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.surfdisp_events_destroy.restype = ctypes.c_int
     L.surfdisp_events_destroy.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.surfdisp_stream_wait_event.restype = ctypes.c_int
+    L.surfdisp_stream_wait_event.argtypes = [vp, vp]
     L.surfdisp_events_elapsed_ms.restype = ctypes.c_int
     L.surfdisp_events_elapsed_ms.argtypes = [vp, vp, fp]
     L.surfdisp_params_to_model_device.restype = ctypes.c_int

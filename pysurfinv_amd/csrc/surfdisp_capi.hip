@@ -408,6 +408,16 @@ int surfdisp_events_destroy(int n, void **events)
     return SURFDISP_SUCCESS;
 }
 
+// make `stream` wait for `event` (recorded on another stream by surfdisp_forward_batch_device_events): lets a caller order
+// the kernels of two solves on two streams, e.g. the Love root search behind the Rayleigh one while the Rayleigh
+// group-velocity kernel fills the rest of the chip (forward.JointPlan)
+int surfdisp_stream_wait_event(void *stream, void *event)
+{
+    if (!event) { set_err("NULL event"); return SURFDISP_ERR_INVALID; }
+    SD_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0));
+    return SURFDISP_SUCCESS;
+}
+
 int surfdisp_events_elapsed_ms(void *start, void *stop, float *ms)
 {
     if (!start || !stop || !ms) { set_err("NULL event"); return SURFDISP_ERR_INVALID; }

@@ -241,18 +241,25 @@ def forward_batch_torch(model, periods, kind=2, nlay=None):
 
 
 class JointPlan:
-    """Rayleigh + Love, phase + group velocity of the same stacks (BASELINE configs[4] shape):
-    two BatchPlans on two HIP streams so the Love kernels fill the machine while the Rayleigh
-    root search drains.  Outputs stay on the device: dict(cR, uR, cL, uL, statusR, statusL)."""
+    """Rayleigh + Love, phase + group velocity of the same stacks (BASELINE configs[4] shape): two BatchPlans on two HIP
+    streams.  ``order``: "concurrent" - both root searches share the chip from the start (each sized for half of it);
+    "rayleigh_first" / "love_first" - the second wave type's kernels wait for the END OF THE FIRST ONE'S ROOT SEARCH
+    (an event recorded between its kernels), so each root search has the whole chip and the first one's group-velocity
+    kernel runs beside the second root search.  Outputs stay on the device: dict(cR, uR, cL, uL, statusR, statusL)."""
 
-    def __init__(self, B, L, P, device="cuda:0"):
+    def __init__(self, B, L, P, device="cuda:0", order=None):
+        import os
         import torch
         self.torch = torch
         self.device = torch.device(device)
+        self.order = order or os.environ.get("SURFDISP_JOINT_ORDER", "concurrent")
+        if self.order not in ("concurrent", "rayleigh_first", "love_first"):
+            raise ValueError("order: concurrent | rayleigh_first | love_first")
         self.ray = BatchPlan(B, L, P, device=device)
         self.love = BatchPlan(B, L, P, device=device)
         self.s_ray = torch.cuda.Stream(device=self.device)
         self.s_love = torch.cuda.Stream(device=self.device)
+        self._ring = EventRing(2)                   # own events when the caller brings none (ordering needs one)
 
     def run(self, model, periods, nlay=None, events=(None, None)):
         """``events``: (Rayleigh, Love) ``EventRing`` slots, recorded on each plan's own stream (measurement)."""
@@ -260,9 +267,29 @@ class JointPlan:
         cur = torch.cuda.current_stream(self.device)
         for s in (self.s_ray, self.s_love):
             s.wait_stream(cur)                       # inputs were produced on the caller's stream
-        with torch.cuda.stream(self.s_ray):
-            cR, uR, sR = self.ray.run(model, periods, kind=_lib.KIND_RAYLEIGH, nlay=nlay, pipelined=True, events=events[0])
-        with torch.cuda.stream(self.s_love):
-            cL, uL, sL = self.love.run(model, periods, kind=_lib.KIND_LOVE, nlay=nlay, pipelined=True, events=events[1])
+        evR = events[0] if events[0] is not None else self._ring.slot(0)
+        evL = events[1] if events[1] is not None else self._ring.slot(1)
+        conc = self.order == "concurrent"
+
+        def ray():
+            with torch.cuda.stream(self.s_ray):
+                return self.ray.run(model, periods, kind=_lib.KIND_RAYLEIGH, nlay=nlay, pipelined=conc, events=evR)
+
+        def love():
+            with torch.cuda.stream(self.s_love):
+                return self.love.run(model, periods, kind=_lib.KIND_LOVE, nlay=nlay, pipelined=conc, events=evL)
+
+        def wait(stream, ev):                        # ev[2]: recorded after the root search of the other solve
+            _lib.check(_lib.lib().surfdisp_stream_wait_event(ctypes.c_void_p(stream.cuda_stream), ev[2]))
+
+        if self.order == "love_first":
+            cL, uL, sL = love()
+            wait(self.s_ray, evL)
+            cR, uR, sR = ray()
+        else:
+            cR, uR, sR = ray()
+            if not conc:
+                wait(self.s_love, evR)
+            cL, uL, sL = love()
         cur.wait_stream(self.s_ray); cur.wait_stream(self.s_love)
         return dict(cR=cR, uR=uR, cL=cL, uL=uL, statusR=sR, statusL=sL)

@@ -43,6 +43,8 @@ class MetropolisBatch:
     reference uses a masked array, point.py:23-26).
     """
 
+    AUTO_INDEP_CHAINS = 3072        # 64-lane teams of fewer chains leave the chip's 196 608 lanes partly empty
+
     def __init__(self, spec: ParamSpec, to_model, periods, c_obs, uncer, device="cuda:0",
                  isgood=None, proposer=None, seed=None, forward=None, independent=False, fast_scan=False,
                  local_rows=None):
@@ -62,8 +64,17 @@ class MetropolisBatch:
         self._plan = None
         self._forward = forward                                 # test hook: callable(model, nlay) -> (c, status)
         # independent=True: period-parallel root search (SURFDISP_INDEPENDENT) - lower latency for few
-        # chains; only for smooth parameterisations (no low-velocity roughness), see include/surfdisp.h
-        self.independent = bool(independent)
+        # chains; only for smooth parameterisations (no low-velocity roughness), see include/surfdisp.h.
+        # independent="auto": that decomposition whenever the lock step is too small to fill the chip with whole-stack
+        # teams (fewer than AUTO_INDEP_CHAINS chains: 100 chains x 96 layers take 0.92 ms per step in the faithful period
+        # walk - a 19-period dependent chain on 100 of 4 096 wavefront slots - against 0.3 ms), the faithful walk
+        # otherwise.  NOT the default: the two agree to 4e-6 with identical zero patterns on 40 000 prior draws of the
+        # continental and the thermal model (scripts/indep_vs_faithful.py, profiles/r03a), but on rough stacks the
+        # reference's answer depends on its period list (start rule 0.9 c(k-1), stale deep layers: up to 2.4e-3,
+        # tests/test_gpu_parity.py) and a default must not change results with the number of chains.
+        if independent not in (True, False, "auto"):
+            raise ValueError("independent must be True, False or 'auto'")
+        self.independent = independent
         # fast_scan=True: opt into the heuristic coarse-to-fine scan (SURFDISP_FASTSCAN); the default walks every
         # grid point of the reference's scan, so root selection and failures are the reference's on every input
         self.fast_scan = bool(fast_scan)
@@ -98,8 +109,9 @@ class MetropolisBatch:
         if self.event_ring is not None:
             ev = self.event_ring.slot(self._ev_i)
             self._ev_i += 1
+        indep = (C < self.AUTO_INDEP_CHAINS) if self.independent == "auto" else bool(self.independent)
         c, _, st = self._plan.run(model.contiguous(), self.periods, kind=_lib.KIND_RAYLEIGH | _lib.PHASE_ONLY,
-                                  nlay=nlay, independent=self.independent, fast_scan=self.fast_scan, events=ev)
+                                  nlay=nlay, independent=indep, fast_scan=self.fast_scan, events=ev)
         return c.to(torch.float64), st
 
     def misfit(self, params, rows=None, return_c=False):

@@ -115,6 +115,17 @@ def test_replay_reference_trace_gpu_independent_mode():
 
 
 @pytest.mark.gpu
+def test_replay_reference_trace_gpu_auto_decomposition():
+    """independent="auto" (opt-in): one chain is far below AUTO_INDEP_CHAINS, so the (stack, period) decomposition runs -
+    and the reference's trace is still reproduced step for step; a batch above the threshold takes the faithful walk."""
+    track, mc = replay("cuda:0", None, independent="auto")
+    check_trace(track)
+    assert MetropolisBatch.AUTO_INDEP_CHAINS == 3072
+    with pytest.raises(ValueError):
+        replay("cuda:0", None, independent="sometimes")
+
+
+@pytest.mark.gpu
 def test_gpu_sampler_statistics_match_reference_trace():
     """512 chains x 80 steps on the GPU vs the reference's 3 chains: same acceptance behaviour
     (rate within a generous band) and the best misfit found is at least as good."""
