@@ -373,11 +373,24 @@ def workload_grid(rt, args, steps=None, warmup=None):
     C = pts * chains
     state = {}
 
+    fused = mc.fused_available() and os.environ.get("BENCH_GRID_FUSED", "1") == "1"
+    track_row = torch.zeros((C, 3 + mb.spec.n), dtype=torch.float64, device=rt.dev)
+
     def setup():
-        state["p"] = mc.reset(C)
-        state["chi"] = mc.misfit(state["p"])[1]
+        state["p"] = mc.reset(C).contiguous()
+        if fused:
+            mc.fused_step(state["p"], first=True)          # chi-square of the start models into the sampler's state
+        else:
+            state["chi"] = mc.misfit(state["p"])[1]
+
+    def step_fused():
+        # the lock step as the library runs it (MetropolisBatch.run): propose kernel, parameters -> stacks, prep / root
+        # search / finish, accept kernel (misfit, accept rule, state update, mcTrack row)
+        mc.fused_step(state["p"], row=track_row, row_stride=3 + mb.spec.n)
 
     def step():
+        if fused:
+            return step_fused()
         p1 = mc.perturb(state["p"])
         mis1, chi1, L1 = mc.misfit(p1)
         better = chi1 < state["chi"]
@@ -395,7 +408,7 @@ def workload_grid(rt, args, steps=None, warmup=None):
     kms = mc.event_ring.kernel_ms().mean(axis=0)
     mc.event_ring = None
     L = int(mb.to_model(state["p"][:4])[0].shape[2])
-    acc_rate, = rt.max_over_ranks(float(state["acc"].double().mean()))
+    acc_rate, = rt.max_over_ranks(float((track_row[:, 2] if fused else state["acc"].double()).mean()))
     per_rank_ms, = rt.max_over_ranks(elapsed / K * 1e3)
     team = int(_lib.lib().surfdisp_get_team(C, L))         # (Rayleigh c+U sizing; phase-only calls may choose narrower)
     return {"metric": "Metropolis steps/s, model3D grid share (BASELINE configs[3])", "unit": "steps/s",
@@ -407,6 +420,8 @@ def workload_grid(rt, args, steps=None, warmup=None):
             "ms_per_step": elapsed / K * 1e3, "steps": K, "warmup": W, "n_gpus": rt.world, "scaling": "weak",
             "config": {"workload": "BASELINE configs[3] share per GPU: 512 points x 50 chains, 96-layer continental model, "
                                    "19 periods, Rayleigh phase-only misfit, default scan",
+                       "lock_step": ("fused: propose kernel, parameters->stacks, prep / root search / finish, accept kernel"
+                                     if fused else "torch glue around the solver"),
                        "points_per_gpu": pts, "chains_per_point": chains, "chains_per_gpu": C, "layers": L,
                        "periods": len(MCMC_PERIODS)},
             "accept_rate_last_step": acc_rate, "forward_solves_timed_this_rank": int(mc.n_forward - n0)}

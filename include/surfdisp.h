@@ -194,6 +194,25 @@ int surfdisp_params_to_model_thermal_device(void *stream, int C, int N, int L, c
                                             const int *idesc, const double *fdesc,
                                             void *scratch, size_t scratch_bytes, float *model);
 
+/* ---- (6b) the Metropolis glue of one lock step on the device (csrc/surfdisp_mcmc.hip).
+ *   propose: every random-walk scalar of every chain moves by a bounded Gaussian step, redrawn while it falls outside
+ *            (vmin, vmax), at most 1000 tries, then a uniform draw (BrownianVar.move, brownian.py:20-27); reset != 0: a
+ *            uniform prior draw for every entry (MCinv.reset, models.py:206-219).  p, out [C][N]; vmin, vmax, step [N].
+ *   accept : misfit of the proposals' predicted curves c[C][P] (fp32, as the solver returns them) against the
+ *            observations (chi2 = sum(((cO-cP)/uncer)^2) over the masked-in periods, misfit = sqrt(chi2/N), chi2 :=
+ *            sqrt(50 chi2) when >= 50, L = exp(-chi2/2); a failed solve = (88888, 88888, 0): point.py:15-31), accept rule
+ *            chi1 < chi0 or u > 1 - exp(-(chi1-chi0)/2) (point.py:34-37), p0 / chi0 updated in place, and the mcTrack row
+ *            [misfit, L, accepted, *proposal] (models.py:254-256) written to row + chain * row_stride (doubles) if row.
+ *            c_obs / uncer / mask are [P], or [C][P] with obs_per_chain.  first != 0: a chain's first row (accepted).
+ *   Random numbers: Philox4x32-10 keyed by `seed`; the caller passes a fresh `counter` per call.  Device pointers,
+ *   stream-ordered, no host synchronisation, graph-capturable. */
+int surfdisp_mcmc_propose_device(void *stream, int C, int N, const double *p, const double *vmin, const double *vmax,
+                                 const double *step, unsigned long long seed, unsigned long long counter, int reset, double *out);
+int surfdisp_mcmc_accept_device(void *stream, int C, int N, int P, const float *c, const int *status,
+                                const double *c_obs, const double *uncer, const unsigned char *mask, int obs_per_chain,
+                                const double *p1, double *p0, double *chi0, double *row, long row_stride,
+                                unsigned long long seed, unsigned long long counter, int first);
+
 /* ---- (7) introspection of the two-tier root search.  The production kernel hands the stacks it cannot treat
  *          faithfully to an exact fallback kernel that runs right behind it inside the same call: a secular
  *          function that leaves the fp32 range (the reference's overflow points depend on how it forms its matrix

@@ -30,6 +30,7 @@ EXPORTS = (
     "surfdisp_forward_batch_device_events", "surfdisp_events_create", "surfdisp_events_destroy",
     "surfdisp_events_elapsed_ms", "surfdisp_stream_wait_event", "surfdisp_params_to_model_device",
     "surfdisp_params_to_model_thermal_device", "surfdisp_thermal_scratch_bytes",
+    "surfdisp_mcmc_propose_device", "surfdisp_mcmc_accept_device",
     "surfdisp_forward_kernels_device", "surfdisp_kernels_workspace_bytes", "surfdisp_workspace_fallback_count", "surfdisp_set_team", "surfdisp_get_team",
     "surfdisp_device_count", "surfdisp_abi_version", "surfdisp_last_error",
     "surfdisp_kernel_name",
@@ -107,6 +108,12 @@ def lib() -> ctypes.CDLL:
     L.surfdisp_params_to_model_thermal_device.restype = ctypes.c_int
     L.surfdisp_params_to_model_thermal_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp,
                                                           vp, ctypes.c_size_t, vp]
+    u64 = ctypes.c_ulonglong
+    L.surfdisp_mcmc_propose_device.restype = ctypes.c_int
+    L.surfdisp_mcmc_propose_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, u64, u64, ctypes.c_int, vp]
+    L.surfdisp_mcmc_accept_device.restype = ctypes.c_int
+    L.surfdisp_mcmc_accept_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int,
+                                              vp, vp, vp, vp, ctypes.c_long, u64, u64, ctypes.c_int]
     L.surfdisp_workspace_fallback_count.restype = ctypes.c_int
     L.surfdisp_workspace_fallback_count.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip]
     L.surfdisp_set_team.restype = ctypes.c_int

@@ -83,6 +83,7 @@ class TorchProposer:
             self.gen.manual_seed(int(seed))
         else:
             self.gen.seed()
+        self.seed_int = int(self.gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF     # key of the fused device kernels' Philox stream
 
     def reset(self, B):
         torch = self.torch

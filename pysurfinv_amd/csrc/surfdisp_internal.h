@@ -88,6 +88,31 @@ struct LayersArgs {
     float *model;          // [C][5][L]
     double *scratch;       // [C][64][2] (vs, qs) of the thermal layer's grid points, or nullptr
 };
+struct McmcProposeArgs {
+    int C, N;
+    const double *p;        // [C][N] current parameters
+    const double *vmin, *vmax, *step;   // [N]
+    unsigned long long seed, counter;
+    int reset;              // 1: uniform prior draw for every entry (MCinv.reset), 0: bounded Gaussian step
+    double *out;            // [C][N]
+};
+struct McmcAcceptArgs {
+    int C, N, P;
+    const float *c;         // [C][P] predicted phase velocities of the proposals
+    const int *status;      // [C] or nullptr
+    const double *c_obs, *uncer;   // [P], or [C][P] when obs_per_chain
+    const unsigned char *mask;     // same shape: 1 = the period counts
+    int obs_per_chain;
+    const double *p1;       // [C][N] proposals
+    double *p0;             // [C][N] chain states, updated in place
+    double *chi0;           // [C] chi-square of the states, updated in place
+    double *row;            // nullptr, or row c at row + c * row_stride: [misfit, L, accepted, params of the proposal]
+    long row_stride;        // in doubles
+    unsigned long long seed, counter;
+    int first;              // 1: first row of a chain (always accepted: the start model)
+};
+hipError_t launch_mcmc_propose(hipStream_t s, const McmcProposeArgs &a);
+hipError_t launch_mcmc_accept(hipStream_t s, const McmcAcceptArgs &a);
 hipError_t launch_layers(hipStream_t s, const LayersArgs &a, int L);
 hipError_t launch_thermal(hipStream_t s, const LayersArgs &a);
 

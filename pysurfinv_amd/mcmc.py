@@ -98,20 +98,10 @@ class MetropolisBatch:
             model, nlay = self.to_model(params, self.local_rows if rows is None else self.local_rows[rows])
         else:
             model, nlay = self.to_model(params)
-        self.n_forward += model.shape[0]
         if self._forward is not None:
+            self.n_forward += model.shape[0]
             return self._forward(model, nlay)
-        from .forward import BatchPlan
-        C, _, L = model.shape
-        if self._plan is None or (self._plan.B, self._plan.L) != (C, L):
-            self._plan = BatchPlan(C, L, self.periods.numel(), device=self.device)
-        ev = None
-        if self.event_ring is not None:
-            ev = self.event_ring.slot(self._ev_i)
-            self._ev_i += 1
-        indep = (C < self.AUTO_INDEP_CHAINS) if self.independent == "auto" else bool(self.independent)
-        c, _, st = self._plan.run(model.contiguous(), self.periods, kind=_lib.KIND_RAYLEIGH | _lib.PHASE_ONLY,
-                                  nlay=nlay, independent=indep, fast_scan=self.fast_scan, events=ev)
+        c, st = self._solve_model(model, nlay)
         return c.to(torch.float64), st
 
     def misfit(self, params, rows=None, return_c=False):
@@ -138,6 +128,76 @@ class MetropolisBatch:
         out = (torch.where(failed, big, mis), torch.where(failed, big, chi),
                torch.where(failed, torch.zeros_like(L), L))
         return out + (cP,) if return_c else out
+
+    # ------------------------------------------------------------------ fused device path (csrc/surfdisp_mcmc.hip)
+    def fused_available(self):
+        """The lock step can run as propose kernel -> stacks -> solver -> accept kernel (no torch glue, no host
+        synchronisation): device proposer, no ``isgood`` callback, the HIP forward path."""
+        return (self.isgood is None and isinstance(self.proposer, TorchProposer) and self.device.type == "cuda"
+                and self._forward is None)
+
+    def _fused_buffers(self, C):
+        torch = self.torch
+        st = getattr(self, "_fz", None)
+        if st is None or st["C"] != C:
+            N = self.spec.n
+            st = dict(C=C, p1=torch.empty((C, N), dtype=torch.float64, device=self.device),
+                      chi=torch.zeros(C, dtype=torch.float64, device=self.device),
+                      mask8=self.mask.to(torch.uint8).contiguous(), c_obs=self.c_obs.contiguous(), uncer=self.uncer.contiguous(),
+                      counter=0)
+            self._fz = st
+        return st
+
+    def _solve_raw(self, params, rows=None):
+        """fp32 c[C, P] and status[C] of the solver's own output tensors (no copies) for the stacks of ``params``."""
+        if self.local_rows is not None:
+            model, nlay = self.to_model(params, self.local_rows if rows is None else self.local_rows[rows])
+        else:
+            model, nlay = self.to_model(params)
+        return self._solve_model(model, nlay)
+
+    def _solve_model(self, model, nlay):
+        self.n_forward += model.shape[0]
+        from .forward import BatchPlan
+        C, _, L = model.shape
+        if self._plan is None or (self._plan.B, self._plan.L) != (C, L):
+            self._plan = BatchPlan(C, L, self.periods.numel(), device=self.device)
+        ev = None
+        if self.event_ring is not None:
+            ev = self.event_ring.slot(self._ev_i)
+            self._ev_i += 1
+        indep = (C < self.AUTO_INDEP_CHAINS) if self.independent == "auto" else bool(self.independent)
+        c, _, st = self._plan.run(model.contiguous(), self.periods, kind=_lib.KIND_RAYLEIGH | _lib.PHASE_ONLY,
+                                  nlay=nlay, independent=indep, fast_scan=self.fast_scan, events=ev)
+        return c, st
+
+    def fused_step(self, p, row=None, row_stride=0, first=False):
+        """One Metropolis step of every chain, in place on the state ``p`` [C, N] (float64, contiguous): proposal
+        (``first``: none - the states themselves are evaluated and accepted, a chain's first row), stacks, forward solve,
+        misfit / accept / update.  ``row``: a float64 tensor whose element 0 is where chain 0's mcTrack row goes, chain c's
+        ``row_stride`` doubles further.  Everything stream-ordered on the current stream."""
+        import ctypes
+        torch = self.torch
+        C, N = p.shape
+        st = self._fused_buffers(C)
+        L = _lib.lib()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+        pr = self.proposer
+        st["counter"] += 1
+        with torch.cuda.device(self.device):
+            if first:
+                p1 = p
+            else:
+                p1 = st["p1"]
+                _lib.check(L.surfdisp_mcmc_propose_device(stream, C, N, ptr(p), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step),
+                                                          pr.seed_int, st["counter"], 0, ptr(p1)))
+            c, status = self._solve_raw(p1)
+            _lib.check(L.surfdisp_mcmc_accept_device(stream, C, N, int(self.periods.numel()), ptr(c), ptr(status),
+                                                     ptr(st["c_obs"]), ptr(st["uncer"]), ptr(st["mask8"]),
+                                                     1 if st["c_obs"].ndim == 2 else 0, ptr(p1), ptr(p), ptr(st["chi"]),
+                                                     ptr(row), int(row_stride), pr.seed_int, st["counter"], 1 if first else 0))
+        return p
 
     # ------------------------------------------------------------------ proposals
     def _good(self, p):
@@ -179,7 +239,7 @@ class MetropolisBatch:
         return new
 
     # ------------------------------------------------------------------ the sampler
-    def run(self, n_chains, chainL, init_first=True, priori=False, _init_mask=None, spec_depth=1):
+    def run(self, n_chains, chainL, init_first=True, priori=False, _init_mask=None, spec_depth=1, fused=None):
         """Advance ``n_chains`` chains for ``chainL`` steps each (= MCinvMP with runN = n_chains*chainL).
 
         Returns mcTrack float64 [n_chains, chainL, 3+N]; chain 0 starts at the initial model when
@@ -192,12 +252,24 @@ class MetropolisBatch:
         chain then walks the tree with the usual accept rule: d Metropolis steps per lock step.
         Every proposal is still drawn from q(current state, .) and tested against the current state,
         so the chain is distributed exactly as with d = 1; only the order in which random numbers are
-        consumed differs (the exact-replay path of the reference trace uses d = 1)."""
+        consumed differs (the exact-replay path of the reference trace uses d = 1).
+
+        ``fused`` (default: whenever ``fused_available()``): the lock step as device kernels around the solver
+        (``fused_step``: Philox random numbers keyed by the proposer's seed; same proposal and accept distributions)."""
         if spec_depth > 1 and not priori:
             return self._run_speculative(n_chains, chainL, init_first, _init_mask, int(spec_depth))
         torch = self.torch
         C, N = int(n_chains), self.spec.n
         track = torch.zeros((C, chainL, 3 + N), dtype=torch.float64, device=self.device)
+        if fused is None:
+            fused = self.fused_available() and not priori
+        if fused:
+            # propose / accept kernels around the solver: mcTrack rows are written by the accept kernel itself
+            p = self._start(C, init_first, _init_mask).contiguous().clone()
+            stride = chainL * (3 + N)
+            for i in range(chainL):
+                self.fused_step(p, row=track[0, i], row_stride=stride, first=(i == 0))
+            return track
         p0 = self.reset(C) if not (init_first and C == 1) else None
         if init_first:
             v0 = torch.as_tensor(self.spec.v0, dtype=torch.float64, device=self.device)[None, :]

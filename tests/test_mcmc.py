@@ -253,3 +253,80 @@ def test_speculative_sampler_with_per_chain_observations():
     assert mis2[0] == mis[1] and mis2[1] == mis[2]
     with pytest.raises(ValueError):
         mc.misfit(p[:3])
+
+
+@pytest.mark.gpu
+def test_fused_device_kernels_proposal_and_accept():
+    """csrc/surfdisp_mcmc.hip against the torch formulas: (1) proposals stay inside the bounds with the requested step
+    (plain Gaussian where the bounds are far), uniform resets cover the prior box; (2) misfit, likelihood and the
+    mcTrack row of the accept kernel equal MetropolisBatch.misfit of the same proposals, the state moves exactly where
+    the row says 'accepted', better models are always accepted, failed solves never."""
+    import ctypes
+    from pysurfinv_amd import _lib
+    dev = torch.device("cuda:0")
+    mb = Model1DBatch(CONT, device=dev)
+    C, N, P = 20000, mb.spec.n, len(G["trace/periods"])
+    rng = np.random.default_rng(0)
+    c_obs = np.tile(G["trace/c_obs"], (C, 1)) * (1 + 0.01 * rng.standard_normal((C, 1)))
+    c_obs[::7, 3] = np.nan                                           # masked periods
+    mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], c_obs, np.tile(G["trace/uncer"], (C, 1)), device=dev, seed=11)
+    assert mc.fused_available()
+    L = _lib.lib()
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    pr = mc.proposer
+    v = torch.as_tensor(mb.spec.v0, device=dev)[None, :].repeat(C, 1).contiguous()
+    new = torch.empty_like(v)
+    _lib.check(L.surfdisp_mcmc_propose_device(None, C, N, ptr(v), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step), 11, 1, 0, ptr(new)))
+    torch.cuda.synchronize()
+    assert bool(((new > pr.vmin) & (new < pr.vmax)).all())
+    d = (new - v).cpu().numpy()
+    assert abs(d[:, 4].std() / mb.spec.step[4] - 1) < 0.03 and abs(d[:, 4].mean()) < 3 * mb.spec.step[4] / 100
+    new2 = torch.empty_like(v)
+    _lib.check(L.surfdisp_mcmc_propose_device(None, C, N, ptr(v), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step), 11, 2, 0, ptr(new2)))
+    assert float((new2 - new).abs().max()) > 0                       # another counter, another draw
+    rs = torch.empty_like(v)
+    _lib.check(L.surfdisp_mcmc_propose_device(None, C, N, ptr(v), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step), 11, 3, 1, ptr(rs)))
+    torch.cuda.synchronize()
+    assert bool(((rs >= pr.vmin) & (rs <= pr.vmax)).all()) and abs(rs[:, 3].mean().item() - 35.0) < 0.3
+    # accept kernel: two lock steps through the sampler's own entry, rows compared with the torch misfit
+    p = rs.clone().contiguous()
+    row = torch.zeros((C, 3 + N), dtype=torch.float64, device=dev)
+    mc.fused_step(p, row=row, row_stride=3 + N, first=True)
+    torch.cuda.synchronize()
+    mis, chi, Lk = mc.misfit(rs)
+    assert float((row[:, 0] - mis).abs().max()) < 1e-9 and float((row[:, 1] - Lk).abs().max()) < 1e-12
+    assert bool((row[:, 2] == 1).all()) and torch.equal(row[:, 3:], rs) and torch.equal(p, rs)
+    chi0 = mc._fz["chi"].clone()
+    assert float((chi0 - chi).abs().max()) < 1e-9
+    before = p.clone()
+    mc.fused_step(p, row=row, row_stride=3 + N)
+    torch.cuda.synchronize()
+    prop = row[:, 3:].contiguous()
+    mis1, chi1, L1 = mc.misfit(prop)
+    assert float((row[:, 0] - mis1).abs().max()) < 1e-9 and float((row[:, 1] - L1).abs().max()) < 1e-12
+    acc = row[:, 2] > 0.5
+    assert torch.equal(p[acc], prop[acc]) and torch.equal(p[~acc], before[~acc])
+    assert bool(acc[chi1 < chi0].all())                              # better models are always accepted
+    assert not bool(acc[mis1 >= 88888].any()) or bool((chi0[acc & (mis1 >= 88888)] >= 88888).all())
+    assert 0.05 < float(acc.double().mean()) < 0.95
+    assert float((mc._fz["chi"] - torch.where(acc, chi1, chi0)).abs().max()) < 1e-9
+
+
+@pytest.mark.gpu
+def test_fused_run_records_consistent_rows():
+    """MetropolisBatch.run on the device path: every recorded row's misfit equals the eagerly recomputed misfit of its
+    parameters, rows form a valid chain, acceptance comparable with the torch-glue path."""
+    dev = torch.device("cuda:0")
+    mb = Model1DBatch(CONT, device=dev)
+    kw = dict(device=dev, seed=4)
+    mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], G["trace/c_obs"], G["trace/uncer"], **kw)
+    tr = mc.run(256, 40)
+    assert mc.n_forward == 256 * 40
+    for k in (0, 1, 17, 39):
+        mis, _, Lk = mc.misfit(tr[:, k, 3:].contiguous())
+        assert float((mis - tr[:, k, 0]).abs().max()) < 1e-9, k
+    assert bool((tr[:, 0, 2] == 1).all()) and np.allclose(tr[0, 0, 3:].cpu().numpy(), mb.spec.v0)
+    mc2 = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], G["trace/c_obs"], G["trace/uncer"], **kw)
+    tr2 = mc2.run(256, 40, fused=False)
+    a1, a2 = float(tr[:, 1:, 2].mean()), float(tr2[:, 1:, 2].mean())
+    assert abs(a1 - a2) < 0.05, (a1, a2)
