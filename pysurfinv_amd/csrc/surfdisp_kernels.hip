@@ -953,14 +953,16 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             cj = croot; mmj = mm_frozen;                       // NEVILL's c3, idrop = 1
         } else if (st == ST_REFINE) {
             const float w = cb - p0c;
-            cj = p0c + (float)(j + 1) * (w / (float)(G + 1));
+            cj = p0c + (float)(j + 1) * (w * (1.0f / (float)(G + 1)));
             if (G <= 4 && G > 1 && p0ok && w > 16.0f * CLUSTER_DC) {
                 // small teams: instead of G equidistant points, cluster them around the secant
                 // estimate (spacing CLUSTER_DC).  Delta(c) is smooth across a 0.01 bracket, so the
                 // root normally falls between two neighbours and the next acceptance test passes
                 // (one refine pass instead of two); if it does not, the sign pattern still shrinks
                 // the bracket and the next pass clusters around a better estimate.
-                float ts = -p0d * w / (db - p0d);
+                // (estimates of where to put trial points and of the root inside a bracket <= 0.01 km/s wide: v_rcp_f32
+                // quotients, 1 ulp - an IEEE division is ten instructions, and a dozen of them sat on every pass)
+                float ts = -p0d * w * __builtin_amdgcn_rcpf(db - p0d);
                 // offsets in units of CLUSTER_DC: tight around the estimate, wider outside, so that a
                 // poorer estimate still lands between two points
                 const float off = (G == 4) ? ((j == 0) ? -4.0f : (j == 1) ? -1.0f : (j == 2) ? 1.0f : 4.0f)
@@ -1260,8 +1262,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 // bracket pins the root the reference finds.
                 const float w = cb - p0c, sx = tc - p0c;
                 const float f0 = p0d, f1 = db, f2 = td;
-                float ts = -f0 * w / (f1 - f0);
-                float t = w * (f0 * f2) / ((f1 - f0) * (f1 - f2)) + sx * (f0 * f1) / ((f2 - f0) * (f2 - f1));
+                auto qt = [](float a, float bq) { return a * __builtin_amdgcn_rcpf(bq); };
+                float ts = qt(-f0 * w, f1 - f0);
+                float t = qt(w * (f0 * f2), (f1 - f0) * (f1 - f2)) + qt(sx * (f0 * f1), (f2 - f0) * (f2 - f1));
                 if (!(ts >= 0.0f)) ts = 0.0f;
                 if (!(ts <= w)) ts = w;
                 if (!p0ok) ts = 0.5f * w;                         // magnitudes not comparable: bisect
@@ -1271,10 +1274,10 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 // the estimates agree with each other (ragged fixture, 60 s: c off by 1.8e-6, which |dlnU/dlnc| = 560
                 // turns into 1e-3 of U).  Such a bracket is subdivided again: the slope towards a neighbouring point must
                 // be within a quarter of the slope across the bracket (ordinary brackets: a fraction of a percent).
-                auto bends = [&](float xs, float fs) {
-                    const float sm = (f1 - f0) / w;
-                    const float sn = (xs > w) ? (fs - f1) / (xs - w) : (f0 - fs) / (0.0f - xs);
-                    return !(fabsf(sn - sm) <= 0.25f * fabsf(sm));
+                auto bends = [&](float xs, float fs) {                 // slopes compared without forming them
+                    const float dm = f1 - f0;
+                    const float dn = (xs > w) ? fs - f1 : f0 - fs, hn = (xs > w) ? xs - w : 0.0f - xs;
+                    return !(fabsf(dn * w - dm * hn) <= 0.25f * fabsf(dm * hn));
                 };
                 const bool smooth = inside && !bends(sx, f2);
                 bool agree = smooth && (fabsf(t - ts) <= A.atol);
@@ -1285,7 +1288,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                     // pass of subdivision would (deep stacks: half of the periods took that extra pass for the
                     // secant's sake, 28 of a stack's 95 passes instead of 19).
                     const float sx2 = uc - p0c, f3 = ud;
-                    const float t2 = w * (f0 * f3) / ((f1 - f0) * (f1 - f3)) + sx2 * (f0 * f1) / ((f3 - f0) * (f3 - f1));
+                    const float t2 = qt(w * (f0 * f3), (f1 - f0) * (f1 - f3)) + qt(sx2 * (f0 * f1), (f3 - f0) * (f3 - f1));
                     agree = (t2 >= 0.0f) && (t2 <= w) && (fabsf(t - t2) <= A.atol);
                 }
                 ++passes;                                          // hard bound: fp32 cannot resolve <1 ulp
