@@ -457,6 +457,8 @@ def workload_mcmc(rt, args, steps=None, warmup=None):
                 "independent_auto_note": "opt-in: MetropolisBatch(independent='auto') / Point.MCinvMP(independent='auto'); "
                                          "equal to the faithful walk to 4e-6 on this model (scripts/indep_vs_faithful.py)"})
     try:
+        if os.environ.get("BENCH_MCMC_NO_GRAPH") == "1":   # counter passes: rocprofv3 --pmc and HIP-graph replay do not mix
+            raise RuntimeError("skipped (BENCH_MCMC_NO_GRAPH=1)")
         mc.run_graphed(100, 8); rt.barrier()
         t0 = time.perf_counter(); mc.run_graphed(100, 4 * K + 2); rt.barrier()
         dtg, = rt.max_over_ranks(time.perf_counter() - t0)
