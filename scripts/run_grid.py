@@ -5,7 +5,9 @@
         scripts/run_grid.py --input grid.npz --setting setting.json --outdir mcdata [--chains 50 --chainL 1000]
     python scripts/run_grid.py --synthetic 64 --outdir mcdata            # one GPU, synthetic observations
 
-``--input``: npz with lons[n], lats[n], periods[P], c_obs[n, P], uncer[n, P] (NaN = masked period).
+``--input``: npz with lons[n], lats[n], periods[P], c_obs[n, P], uncer[n, P] (NaN = masked period) and, with
+``--local-keys topo,lithoAge,...``, local_info[n, K]: every point's own constants (what the reference passes as
+``Point(setting, localInfo)``, point.py:8-14; columns in the order of ``--local-keys``).
 ``--setting``: the reference's model setting as JSON (``models.py:42-51``; default: the continental example of
 ``pysurfinv_amd.settings``).  Every rank inverts its block of points (``pysurfinv_amd.grid.run_grid``), writes
 ``{outdir}/{lon}_{lat}.npz`` with the reference's keys - what ``Model3D.loadInvDir`` (``model3D.py:36-57``) reads - and
@@ -34,6 +36,8 @@ def main():
     ap.add_argument("--chainL", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--fast-scan", action="store_true", help="opt into the heuristic scan (SURFDISP_FASTSCAN)")
+    ap.add_argument("--local-keys", default="", help="comma-separated per-point constants (topo, lithoAge, period, <Layer>.<key>): "
+                                                     "columns of local_info[n, K] in --input")
     args = ap.parse_args()
 
     import torch
@@ -56,17 +60,22 @@ def main():
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
     setting = json.load(open(args.setting)) if args.setting else settings.MCMC_SETTING
-    mb = Model1DBatch(setting, device=dev)
+    local_keys = [k for k in args.local_keys.split(",") if k]
+    mb = Model1DBatch(setting, device=dev, local_keys=local_keys)
+    local_info = None
     if args.input:
         z = np.load(args.input)
         lons, lats, periods, c_obs, uncer = z["lons"], z["lats"], z["periods"], z["c_obs"], z["uncer"]
+        if local_keys:
+            local_info = z["local_info"]
     else:
         n = max(1, args.synthetic)
         _, c_obs, uncer = settings.synthetic_observations(n, dev)
         periods = np.asarray(settings.MCMC_PERIODS, float)
         lons, lats = 230.0 + 0.5 * (np.arange(n) % 64), 40.0 + 0.5 * (np.arange(n) // 64)
     r = grid.run_grid(mb, lons, lats, periods, c_obs, uncer, args.chains, args.chainL, outdir=args.outdir,
-                      rank=rank, world=world, device=str(dev), seed=args.seed, fast_scan=args.fast_scan, keep_tracks=False)
+                      rank=rank, world=world, device=str(dev), seed=args.seed, fast_scan=args.fast_scan, keep_tracks=False,
+                      local_info=local_info)
     if rank == 0:
         os.makedirs(args.outdir, exist_ok=True)
         np.savez_compressed(os.path.join(args.outdir, "summaries.npz"), summaries=r["summaries"], columns=np.array(r["columns"]),
