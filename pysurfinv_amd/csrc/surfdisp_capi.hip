@@ -19,6 +19,7 @@ std::atomic<double *> g_dbg{nullptr};    // developer hook, see surfdisp_debug_b
 // environment knobs, read ONCE per process (a getenv per launch is visible in launch-bound Metropolis loops)
 struct EnvKnobs {
     int team = 0;                 // SURFDISP_TEAM
+    int team_love = 0;            // SURFDISP_TEAM_LOVE (developer knob): lanes per stack of Love root searches only
     size_t overlap_max = 64u * 1024u;   // SURFDISP_OVERLAP_MAX
     size_t lds_budget = 44u * 1024u;    // SURFDISP_LDS_BUDGET (developer knob): root-search LDS per 256 lanes
     float refine_wtol = 1.2e-3f;  // SURFDISP_WTOL
@@ -31,6 +32,7 @@ struct EnvKnobs {
     EnvKnobs()
     {
         if (const char *e = getenv("SURFDISP_TEAM")) team = atoi(e);
+        if (const char *e = getenv("SURFDISP_TEAM_LOVE")) team_love = atoi(e);
         if (const char *e = getenv("SURFDISP_OVERLAP_MAX")) overlap_max = (size_t)atol(e);
         if (const char *e = getenv("SURFDISP_LDS_BUDGET")) lds_budget = (size_t)atol(e);
         if (const char *e = getenv("SURFDISP_WTOL")) refine_wtol = (float)atof(e);
@@ -91,9 +93,10 @@ Carve carve(void *base, int B, int Lmax, int P)
     return c;
 }
 
-int pick_team(int B, int Lmax, bool need_ratio = true, bool pipelined = false)
+int pick_team(int B, int Lmax, bool need_ratio = true, bool pipelined = false, int kind = SURFDISP_KIND_RAYLEIGH)
 {
     int G = g_team_override.load(std::memory_order_relaxed);
+    if (G == 0 && kind == SURFDISP_KIND_LOVE) G = knobs().team_love;
     if (G == 0) G = knobs().team;
     if (G == 0) {
         // measured on MI355X (scripts/sweep_team.py, profiles/r02e/sweep_team.txt): at least three wavefronts per
@@ -103,6 +106,13 @@ int pick_team(int B, int Lmax, bool need_ratio = true, bool pipelined = false)
         G = 2;
         while (G < 64 && (long)B * G < target) G *= 2;
     }
+    // Love evaluations are cheap (a 2-vector recursion, ~35 instructions per layer against Rayleigh's ~95), so a pass's team
+    // bookkeeping weighs more and wider teams = fewer passes win: never fewer than 8 lanes (65 536 x L10: 0.82 -> 0.70 ms), and
+    // the caller sizes a Love launch for its own stacks even beside another stream's kernels (forward_device_impl: 16 384 x L64
+    // beside the Rayleigh root search of a joint solve, teams of 16 instead of 8: 6.59 -> 6.24 ms); measured with the four-field
+    // Love working stack, scripts/sweep_team.py, profiles/r03a/love_team.txt
+    if (kind == SURFDISP_KIND_LOVE && !g_team_override.load(std::memory_order_relaxed) && !knobs().team && !knobs().team_love && G < 8)
+        G = 8;
     if (G < 1) G = 1;
     if (G > 64) G = 64;
     int p2 = 1;
@@ -117,7 +127,7 @@ int pick_team(int B, int Lmax, bool need_ratio = true, bool pipelined = false)
     // (a caller that keeps another batch in flight - SURFDISP_PIPELINED, the joint Rayleigh + Love plan - has the other
     // stream's wavefronts to fill a SIMD: there the narrower team's fewer evaluations win, 64 KB = two workgroups)
     const size_t budget = pipelined ? (knobs().lds_budget * 16) / 11 : knobs().lds_budget;
-    auto lds_of = [&](int g) { return sd::phase_lds_bytes(Lmax, g, need_ratio && g >= 4) * per256; };
+    auto lds_of = [&](int g) { return sd::phase_lds_bytes(Lmax, g, need_ratio && g >= 4, kind) * per256; };
     while (G < 64 && lds_of(G) > budget) G *= 2;
     return G;
 }
@@ -128,7 +138,7 @@ int pick_team(int B, int Lmax, bool need_ratio = true, bool pipelined = false)
 static bool use_overlap(int Lmax, int G)
 {
     const size_t cap = knobs().overlap_max;
-    return G >= 4 && sd::phase_lds_bytes(Lmax, G, true) * (256 / SD_PHASE_BLOCK) <= cap;
+    return G >= 4 && sd::phase_lds_bytes(Lmax, G, true, SURFDISP_KIND_RAYLEIGH) * (256 / SD_PHASE_BLOCK) <= cap;
 }
 
 int check_args(int B, int Lmax, int P, int kind, const void *model, const void *per,
@@ -241,8 +251,8 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     const Carve w = carve(workspace, B, Lmax, P);
     // independent mode has B*P root searches in flight: size the teams for that many; a caller that
     // keeps a second batch in flight (SURFDISP_PIPELINED) has twice the stacks on the chip
-    const long units = (indep ? (long)B * P : (long)B) * (pipelined ? 2 : 1);
-    const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax, want_ell, pipelined);
+    const long units = (indep ? (long)B * P : (long)B) * ((pipelined && kind != SURFDISP_KIND_LOVE) ? 2 : 1);
+    const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax, want_ell, pipelined, kind);
 
     // Staged copy of the model the root search rebuilds its working stack from, once per period: with >= 8 lanes per
     // stack consecutive lanes take consecutive layers, so the fields are laid out one row per stack (coalesced; from the

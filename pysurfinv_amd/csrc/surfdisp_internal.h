@@ -122,9 +122,9 @@ hipError_t launch_thermal(hipStream_t s, const LayersArgs &a);
 #ifndef SD_PHASE_BLOCK
 #define SD_PHASE_BLOCK 256
 #endif
-size_t phase_lds_bytes(int Lmax, int G, bool overlap);   // per workgroup of SD_PHASE_BLOCK lanes
-size_t phase_exact_lds_bytes(int Lmax, int G);
-int phase_exact_team(int Lmax);                          // lanes per stack of the exact fallback kernel
+size_t phase_lds_bytes(int Lmax, int G, bool overlap, int kind);   // per workgroup of SD_PHASE_BLOCK lanes (kind: 1 Love, 2 Rayleigh)
+size_t phase_exact_lds_bytes(int Lmax, int G, int kind);
+int phase_exact_team(int Lmax, int kind);                // lanes per stack of the exact fallback kernel
 hipError_t launch_phase_exact(hipStream_t s, int kind, bool independent, const PhaseArgs &a);
 hipError_t launch_finish(hipStream_t s, const FinishArgs &a);
 hipError_t launch_kern_transpose(hipStream_t s, const float *scr, float *out, int B, int P, int Lmax);

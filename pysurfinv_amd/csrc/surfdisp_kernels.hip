@@ -268,15 +268,20 @@ constexpr int NFW = 6;
 // up to 16 lanes: unpadded, all lanes of a team hit ONE bank (16-way conflicts on each of the 36 writes of a rebuild;
 // SQ_LDS_BANK_CONFLICT was 29-55 % of the LDS cycles, profiles/r03a).  Wanted: lane j, neighbouring slot t -> bank
 // (j * LS + t) mod 32 all different, i.e. LS = q * odd (mod 32) with q = 32 / G slots per group (1 for G >= 32).
-SD_HD constexpr int lds_ls(int S)
+// Love needs four of the six fields (1/(rho b^2), b, rho, d: 1/b^2 = 1/(rho b^2) x rho is one multiplication in the
+// recursion): its working stacks take two thirds of the LDS - what decides how many Love workgroups fit beside the
+// Rayleigh ones of a joint solve.
+constexpr int NFW_LOVE = 4;
+SD_HD constexpr int lds_ls(int S, int NF = NFW)
 {
     const int G = SD_PHASE_BLOCK / S;
     const int q = (G >= 32) ? 1 : 32 / G;
-    int ls = NFW * S;
+    int ls = NF * S;
     while (ls % (2 * q) != q) ++ls;
     return ls;
 }
-#define W_AT(m, f) wq[(m) * lds_ls(S) + (f) * S]
+// LS: the layer stride of the working stack at hand (a variable or parameter of the code that uses the macros)
+#define W_AT(m, f) wq[(m) * LS + (f) * S]
 #define W_IR(m) W_AT(m, 0)    // Rayleigh: layer 0 1/rho, layer m >= 1 rho(m-1)/rho(m) (rescale factor of the carried state); Love: 1/(rho b^2)
 #define W_B(m) W_AT(m, 1)
 #define W_R(m) W_AT(m, 2)
@@ -351,7 +356,7 @@ __device__ __forceinline__ void sincos_cw(float x, float *sn, float *cs)
 // Vertical wavenumbers ra, rb and their reciprocals come from ONE v_rsq_f32 each; sinh/cosh from two v_exp_f32.
 // (The reference's own arithmetic, statement by statement, is delta_rayleigh_ref below: the exact fallback kernel.)
 template <bool PIPE2 = true>
-__device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap, const int S,
+__device__ __forceinline__ float delta_rayleigh(const float *wq, const int LS, const int S,
                                                 const int mmax, const float c, const float T,
                                                 const int start, float &phi)
 {
@@ -516,7 +521,7 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int Lcap,
 // overflows to inf, and every inf - inf turns NaN, exactly where the reference's does (which decides the "roots" the
 // reference returns next to the overflowed region).  Working stack of that kernel: a in the W_IA2 slot.
 // start = 1 -> dispersion (-bb1); 2 / 3 -> the two ellipticity passes (bb1), combined by the caller (surfa.f:360-363).
-__device__ __noinline__ float delta_rayleigh_ref(const float *wq, const int Lcap, const int S,
+__device__ __noinline__ float delta_rayleigh_ref(const float *wq, const int LS, const int S,
                                                  const int mmax, const float c, const float t, const int start)
 {
 #pragma clang fp contract(off)
@@ -608,7 +613,7 @@ __device__ __noinline__ float delta_rayleigh_ref(const float *wq, const int Lcap
 // from zero: c == b then runs through the oscillatory formulas with rb = 1e-15, which give the reference's degenerate
 // values y = -k d, z = 0, cosq = 1 of surfa.f:163-165 to 1e-15); 1/(rho b^2) comes from the working stack (the slot the
 // Rayleigh recursion keeps its density ratios in).  Three transcendentals per evanescent layer instead of five.
-__device__ __forceinline__ float delta_love(const float *wq, const int Lcap, const int S,
+__device__ __forceinline__ float delta_love(const float *wq, const int LS, const int S,
                                             const int mmax, const float c, const float T, float &phi)
 {
     phi = 0.0f;                                            // see delta_rayleigh
@@ -617,17 +622,17 @@ __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, con
     const int mh = mmax - 1;
     float bm = W_B(mh);
     float h = W_R(mh) * bm * bm;
-    float rb = sqrt_hw(fabsf(fmaf(csq, W_IB2(mh), -1.0f)));          // sqrt|c^2/b^2 - 1|
+    float rb = sqrt_hw(fabsf(fmaf(csq, W_IR(mh) * W_R(mh), -1.0f)));   // sqrt|c^2/b^2 - 1|, 1/b^2 = 1/(rho b^2) x rho
     float ut = 1.0f, tt = h * rb;
     // layer m-1's five LDS values are in flight while layer m is computed; unrolled by two over
     // alternating register sets
-    struct Lyr { float b, d, ib2, r, ih; };
-    auto load = [&](int m) -> Lyr { const int q = m > 0 ? m : 0; return {W_B(q), W_D(q), W_IB2(q), W_R(q), W_IR(q)}; };
+    struct Lyr { float b, d, r, ih; };
+    auto load = [&](int m) -> Lyr { const int q = m > 0 ? m : 0; return {W_B(q), W_D(q), W_R(q), W_IR(q)}; };
     auto step = [&](const Lyr &y) {
         bm = y.b;
-        const float d = y.d, ib2 = y.ib2, rho = y.r, ih = y.ih;
+        const float d = y.d, rho = y.r, ih = y.ih;
         if (bm == 0.0f) return;                            // water, surfa.f:152
-        const float arg = fmaf(csq, ib2, -1.0f);           // c^2/b^2 - 1: < 0 evanescent
+        const float arg = fmaf(csq, ih * rho, -1.0f);      // c^2/b^2 - 1: < 0 evanescent
         const float x = fmaxf(fabsf(arg), 1.0e-30f), irb = __builtin_amdgcn_rsqf(x);
         rb = x * irb;
         h = rho * bm * bm;
@@ -661,7 +666,7 @@ __device__ __forceinline__ float delta_love(const float *wq, const int Lcap, con
 }
 
 // ... and its Love secular function: DLTAR1 statement by statement (surfa.f:143-179), same rules.
-__device__ __noinline__ float delta_love_ref(const float *wq, const int Lcap, const int S,
+__device__ __noinline__ float delta_love_ref(const float *wq, const int LS, const int S,
                                              const int mmax, const float c, const float t)
 {
 #pragma clang fp contract(off)
@@ -699,7 +704,7 @@ __device__ __noinline__ float delta_love_ref(const float *wq, const int Lcap, co
 // layer dropping for one trial velocity, surfa.f:94-105.  No early exit: every load is independent
 // of the running sum, so the LDS reads pipeline instead of costing one round trip per layer
 // (adding 0.0f for a skipped layer is exact, and nothing after the first crossing can change mm).
-__device__ __forceinline__ int drop_layers(const float *wq, const int Lcap, const int S,
+__device__ __forceinline__ int drop_layers(const float *wq, const int LS, const int S,
                                            const int n, const float c, const float T)
 {
     // mmax = ii + 1 at the first layer ii whose running sum exceeds dmax.  The thicknesses are >= 0, so the running sums
@@ -747,6 +752,8 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
 {
     extern __shared__ float w_lds[];
     constexpr int S = SD_PHASE_BLOCK / G;                 // stacks (teams) per workgroup
+    constexpr int NFK = (KIND == 1) ? NFW_LOVE : NFW;     // fields per layer of the working stack
+    constexpr int LS = lds_ls(S, NFK);                    // ... and its layer stride (words)
     const int tid = threadIdx.x;
 #ifdef SD_WAVECLOCK
     const unsigned long long wclk0 = __builtin_amdgcn_s_memrealtime();
@@ -778,9 +785,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     // kernel: a phase-only call (A.ratio == nullptr) skips it altogether
     const bool want_ratio = (KIND == 2) && (A.ratio != nullptr);
     const bool OVERLAP = !EXACT && want_ratio && (G >= 4) && !INDEP && (A.overlap != 0);
-    float *wq2 = w_lds + (size_t)lds_ls(S) * Lcap + slot;
+    float *wq2 = w_lds + (size_t)LS * Lcap + slot;
     // NEVILL's interpolation table x(1..11), y(1..11) (surfa.f:8) of this team, behind the working stacks
-    float *nvx = w_lds + (size_t)((!EXACT && G >= 4 && A.overlap != 0) ? 2 : 1) * lds_ls(S) * Lcap + (size_t)slot * 24, *nvy = nvx + 12;
+    float *nvx = w_lds + (size_t)((!EXACT && G >= 4 && A.overlap != 0) ? 2 : 1) * LS * Lcap + (size_t)slot * 24, *nvy = nvx + 12;
     // staged fields of this team's stack (SoA copy or rows, see PhaseArgs): field f of layer i at M_AT(f, i)
     const float *__restrict__ mrow = A.msrc + (size_t)b * A.ms_b;
     const size_t msf = (size_t)A.ms_f, msi = (size_t)A.ms_i;
@@ -844,8 +851,10 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             W_B(i) = v.b; W_R(i) = v.rho; W_D(i) = v.d;
             if (KIND == 1 && !EXACT) W_IR(i) = rcp_nr(v.rho * v.b * v.b);       // Love, production: 1/(rho b^2)
             else if (i == 0 || EXACT) W_IR(i) = rcp_nr(v.rho);
-            W_IA2(i) = (EXACT && KIND == 2) ? v.a : rcp_nr(v.a * v.a);       // exact kernel: a itself (delta_rayleigh_ref)
-            W_IB2(i) = (v.b > 0.0f) ? rcp_nr(v.b * v.b) : 0.0f;
+            if (KIND == 2) {
+                W_IA2(i) = EXACT ? v.a : rcp_nr(v.a * v.a);                      // exact kernel: a itself (delta_rayleigh_ref)
+                W_IB2(i) = (v.b > 0.0f) ? rcp_nr(v.b * v.b) : 0.0f;
+            }
         }
         if (KIND == 2 && !EXACT) {
             // the carried state of delta_rayleigh is rescaled by rho(m-1)/rho(m) on entering layer m: formed here, once
@@ -890,7 +899,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     if (st != ST_DONE) {
         T = A.per[k];
         // clear the slot (a new process sees zeroed COMMON /d/)
-        for (int i = j; i < Lcap; i += G) { W_IR(i) = 0.0f; W_B(i) = 0.0f; W_R(i) = 0.0f; W_D(i) = 0.0f; W_IA2(i) = 0.0f; W_IB2(i) = 0.0f; }
+        for (int i = j; i < Lcap; i += G) { W_IR(i) = 0.0f; W_B(i) = 0.0f; W_R(i) = 0.0f; W_D(i) = 0.0f; if (KIND == 2) { W_IA2(i) = 0.0f; W_IB2(i) = 0.0f; } }
         build(n);
         b1top = W_B(0);
         // first guess, fast_surf.f:157-171
@@ -948,7 +957,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
 #pragma unroll
                 for (int i = 0; i < G; ++i) if (i < nadd) cj = cj + DC;
             }
-            mmj = nodrop ? (n < 2 ? 2 : n) : drop_layers(wq, Lcap, S, n, cj, T);   // idrop=0 before every scan trial
+            mmj = nodrop ? (n < 2 ? 2 : n) : drop_layers(wq, LS, S, n, cj, T);   // idrop=0 before every scan trial
         } else if (st == ST_NEVILL) {
             cj = croot; mmj = mm_frozen;                       // NEVILL's c3, idrop = 1
         } else if (st == ST_REFINE) {
@@ -993,9 +1002,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         }
 #endif
         if (eval) {
-            if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, Lcap, S, mmj, cj, Tl, start)
-                                       : delta_rayleigh<(G != 2) && !FAST>(wl, Lcap, S, mmj, cj, Tl, start, phj);
-            else           val = EXACT ? delta_love_ref(wl, Lcap, S, mmj, cj, Tl) : delta_love(wl, Lcap, S, mmj, cj, Tl, phj);
+            if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, LS, S, mmj, cj, Tl, start)
+                                       : delta_rayleigh<(G != 2) && !FAST>(wl, LS, S, mmj, cj, Tl, start, phj);
+            else           val = EXACT ? delta_love_ref(wl, LS, S, mmj, cj, Tl) : delta_love(wl, LS, S, mmj, cj, Tl, phj);
         }
 #ifdef SD_WAVECLOCK
         wcyc_eval += __builtin_readcyclecounter() - we0;
@@ -1302,8 +1311,8 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                                 // the next build overwrites exactly these (first mm_frozen) layers
                                 for (int i = j; i < mm_frozen; i += G) {
 #pragma unroll
-                                    for (int f = 0; f < NFW; ++f)
-                                        wq2[i * lds_ls(S) + f * S] = wq[i * lds_ls(S) + f * S];
+                                    for (int f = 0; f < NFK; ++f)
+                                        wq2[i * LS + f * S] = wq[i * LS + f * S];
                                 }
                                 ell_pend = true; ell_k = k; ell_mm = mm_frozen; ell_c = croot; ell_T = T;
                                 solved = true;
@@ -2115,7 +2124,7 @@ template <int KIND, int G, bool INDEP, bool FAST = false, bool EXACT = false>
 hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 {
     constexpr int S = SD_PHASE_BLOCK / G;
-    const size_t lds = EXACT ? sd::phase_exact_lds_bytes(a.Lmax, G) : sd::phase_lds_bytes(a.Lmax, G, a.overlap != 0);
+    const size_t lds = EXACT ? sd::phase_exact_lds_bytes(a.Lmax, G, KIND) : sd::phase_lds_bytes(a.Lmax, G, a.overlap != 0, KIND);
     auto kern = sd::surfdisp_phase_kernel<KIND, G, INDEP, FAST, EXACT>;
     // raise the dynamic-LDS limit of this instantiation only when a launch needs more than any before it (per
     // device): the attribute call costs ~10 us, visible in launch-bound Metropolis loops
@@ -2140,7 +2149,7 @@ hipError_t launch_phase_g(hipStream_t s, const sd::PhaseArgs &a)
 template <int KIND, bool INDEP>
 hipError_t launch_phase_x(hipStream_t s, const sd::PhaseArgs &a)
 {
-    switch (sd::phase_exact_team(a.Lmax)) {
+    switch (sd::phase_exact_team(a.Lmax, KIND)) {
         case 16: return launch_phase_g<KIND, 16, INDEP, false, true>(s, a);
         case 32: return launch_phase_g<KIND, 32, INDEP, false, true>(s, a);
         default: return launch_phase_g<KIND, 64, INDEP, false, true>(s, a);
@@ -2177,13 +2186,13 @@ namespace sd {
 // working stack per team (+ the ellipticity snapshot slot for teams of >= 4 lanes; allocated for
 // Love too so that one number describes a launch)
 // NEVILL's table x(12), y(12) per team behind the working stack(s)
-size_t phase_lds_bytes(int Lmax, int G, bool overlap) { const int S = SD_PHASE_BLOCK / G; return ((size_t)((G >= 4 && overlap) ? 2 : 1) * lds_ls(S) * Lmax + (size_t)24 * S) * sizeof(float); }
+size_t phase_lds_bytes(int Lmax, int G, bool overlap, int kind) { const int S = SD_PHASE_BLOCK / G; return ((size_t)((G >= 4 && overlap) ? 2 : 1) * lds_ls(S, kind == 1 ? NFW_LOVE : NFW) * Lmax + (size_t)24 * S) * sizeof(float); }
 // exact fallback: one working stack per team + NEVILL's table x(12), y(12)
-size_t phase_exact_lds_bytes(int Lmax, int G) { const int S = SD_PHASE_BLOCK / G; return ((size_t)lds_ls(S) * Lmax + (size_t)24 * S) * sizeof(float); }
-int phase_exact_team(int Lmax)
+size_t phase_exact_lds_bytes(int Lmax, int G, int kind) { const int S = SD_PHASE_BLOCK / G; return ((size_t)lds_ls(S, kind == 1 ? NFW_LOVE : NFW) * Lmax + (size_t)24 * S) * sizeof(float); }
+int phase_exact_team(int Lmax, int kind)
 {
     int G = 16;
-    while (G < 64 && phase_exact_lds_bytes(Lmax, G) > 64u * 1024u) G *= 2;
+    while (G < 64 && phase_exact_lds_bytes(Lmax, G, kind) > 64u * 1024u) G *= 2;
     return G;
 }
 

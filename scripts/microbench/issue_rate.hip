@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void issue_kernel(float *out, int iters, int L
     constexpr int S = 64;
     const int tid = threadIdx.x, slot = tid / 4, j = tid % 4;
     float *wq = w_lds + slot;
-    const int Lcap = L;
+    const int LS = lds_ls(64);
     for (int i = j; i < L; i += 4) {                       // a 10-layer crust/mantle stack, Vs 3.0 -> 4.6
         const float z = (float)i / (float)(L - 1);
         const float b = 3.0f + 1.6f * z, a = 1.76f * b, rho = 0.541f + 0.3601f * a, d = 200.0f / L;
@@ -35,15 +35,15 @@ __global__ __launch_bounds__(256) void issue_kernel(float *out, int iters, int L
         // two independent evaluations per lane and iteration (instruction-level parallelism 2)
         float c2 = c + 0.005f;
         for (int it = 0; it < iters / 2; ++it) {
-            const float v = delta_rayleigh(wq, Lcap, S, L, c, T, 1, phi_);
-            const float w = delta_rayleigh(wq, Lcap, S, L, c2, T, 1, phi_);
+            const float v = delta_rayleigh(wq, LS, S, L, c, T, 1, phi_);
+            const float w = delta_rayleigh(wq, LS, S, L, c2, T, 1, phi_);
             acc += v + w;
             c += (v > 1e30f) ? 1e-3f : 0.0f;
             c2 += (w > 1e30f) ? 1e-3f : 0.0f;
         }
     } else {
         for (int it = 0; it < iters; ++it) {
-            const float v = delta_rayleigh(wq, Lcap, S, L, c, T, 1, phi_);
+            const float v = delta_rayleigh(wq, LS, S, L, c, T, 1, phi_);
             acc += v;
             c += (v > 1e30f) ? 1e-3f : 0.0f;                  // keeps the loop from being hoisted
         }
