@@ -29,6 +29,7 @@ struct EnvKnobs {
     int device = 0;               // SURFDISP_DEVICE (fast_surf_)
     int balance = -1;             // SURFDISP_BALANCE (developer knob): wavefront priority by progress, -1 = automatic
     int rows_min_team = 8;        // SURFDISP_ROWS_MIN_TEAM (developer knob): teams of at least this many lanes rebuild from the row copy
+    int ell_kernel = 1;           // SURFDISP_ELL_KERNEL (developer knob): 0 = the ellipticity recursions inside the root search (r02)
     EnvKnobs()
     {
         if (const char *e = getenv("SURFDISP_TEAM")) team = atoi(e);
@@ -42,6 +43,7 @@ struct EnvKnobs {
         if (const char *e = getenv("SURFDISP_DEVICE")) device = atoi(e);
         if (const char *e = getenv("SURFDISP_BALANCE")) balance = atoi(e);
         if (const char *e = getenv("SURFDISP_ROWS_MIN_TEAM")) rows_min_team = atoi(e);
+        if (const char *e = getenv("SURFDISP_ELL_KERNEL")) ell_kernel = atoi(e);
     }
 };
 const EnvKnobs &knobs() { static const EnvKnobs k; return k; }
@@ -67,7 +69,7 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct Carve {
     float *mdl, *rows, *ratio, *ct, *ut;
-    int *nl, *nsolved;
+    int *nl, *nsolved, *hist;
     float *fsafe, *ovf;
     int *fb_count, *fb_list;
     size_t total;
@@ -83,6 +85,7 @@ Carve carve(void *base, int B, int Lmax, int P)
     c.ratio = reinterpret_cast<float *>(p + off);   off += align_up((size_t)P * B * sizeof(float));
     c.ct = reinterpret_cast<float *>(p + off);      off += align_up((size_t)P * B * sizeof(float));
     c.ut = reinterpret_cast<float *>(p + off);      off += align_up((size_t)P * B * sizeof(float));
+    c.hist = reinterpret_cast<int *>(p + off);      off += align_up((size_t)P * B * sizeof(int));
     c.nl = reinterpret_cast<int *>(p + off);        off += align_up((size_t)B * sizeof(int));
     c.nsolved = reinterpret_cast<int *>(p + off);   off += align_up((size_t)B * sizeof(int));
     c.fsafe = reinterpret_cast<float *>(p + off);   off += align_up((size_t)B * sizeof(float));
@@ -252,7 +255,15 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     // independent mode has B*P root searches in flight: size the teams for that many; a caller that
     // keeps a second batch in flight (SURFDISP_PIPELINED) has twice the stacks on the chip
     const long units = (indep ? (long)B * P : (long)B) * ((pipelined && kind != SURFDISP_KIND_LOVE) ? 2 : 1);
-    const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax, want_ell, pipelined, kind);
+    // The ellipticities come from their own kernel (one lane per (stack, period), replaying the working stack's history):
+    // the root search then runs as in a phase-only call - no riders, no second LDS slot.  The exact fallback kernel
+    // (and SURFDISP_STRICT) keeps them in-kernel.
+    // Teams of two lanes keep them too: their ellipticity pass has both lanes busy, one start vector each (three batches in
+    // flight, 65 536 x L10: 34.0 M solves/s in-kernel against 33.6 M with the extra kernel).
+    const bool ell_k_ok = want_ell && kn.ell_kernel != 0 && !strict;
+    const int G = pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax, want_ell && !ell_k_ok, pipelined, kind);
+    const bool ell_k = ell_k_ok && G >= 4;
+    const bool ell_in = want_ell && !ell_k;
 
     // Staged copy of the model the root search rebuilds its working stack from, once per period: with >= 8 lanes per
     // stack consecutive lanes take consecutive layers, so the fields are laid out one row per stack (coalesced; from the
@@ -261,25 +272,31 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     // lane per (stack, period) - always reads the SoA copy; a phase-only call with rows skips writing it (the exact
     // fallback launch reads whatever the production launch read).
     const bool use_rows = (G >= kn.rows_min_team);
-    const bool need_soa = !use_rows || !phase_only;
+    const bool need_soa = !use_rows || !phase_only || want_ell;
     sd::PrepArgs pa{B, Lmax, nlay, model, w.mdl, w.nl, P, indep ? w.nsolved : nullptr, w.fsafe, w.ovf, w.fb_count,
                     use_rows ? w.rows : nullptr, need_soa ? 1 : 0};
     if (ev) SD_HIP(hipEventRecord(ev[0], s));
     SD_HIP(sd::launch_prep(s, kind, pa));
     if (ev) SD_HIP(hipEventRecord(ev[1], s));
     const float wtol = kn.refine_wtol, atol = kn.refine_atol, phimax = kn.phimax;
-    sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, want_ell ? w.ratio : nullptr, w.nsolved, status, wtol, atol,
-                     fastscan ? 1 : 0, w.fsafe, (want_ell && use_overlap(Lmax, G)) ? 1 : 0, phimax,
+    sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, ell_in ? w.ratio : nullptr, w.nsolved, status, wtol, atol,
+                     fastscan ? 1 : 0, w.fsafe, (ell_in && use_overlap(Lmax, G)) ? 1 : 0, phimax,
                      w.ovf, w.fb_count, w.fb_list, kn.balance >= 0 ? kn.balance : (pipelined ? 0 : 1), strict ? 1 : 0};
 #ifdef SD_WAVECLOCK
     ph.wclk = reinterpret_cast<unsigned long long *>(g_dbg.load(std::memory_order_relaxed));
 #endif
     if (use_rows) { ph.msrc = w.rows; ph.ms_b = 9L * Lmax; ph.ms_f = Lmax; ph.ms_i = 1; }
     else          { ph.msrc = w.mdl;  ph.ms_b = 1;         ph.ms_f = (long)Lmax * B; ph.ms_i = B; }
+    ph.hist = ell_k ? w.hist : nullptr;
     SD_HIP(sd::launch_phase(s, kind, G, indep, ph));
     // the exact fallback re-solves what the production kernel listed (normally nothing: idle blocks exit at once)
     ph.overlap = 0; ph.fast = 0;
+    if (ell_k) ph.ratio = w.ratio;                         // ... with its ellipticities in-kernel (marked -1 in hist)
     SD_HIP(sd::launch_phase_exact(s, kind, indep, ph));
+    if (ell_k) {
+        sd::EllipArgs ea{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.hist, w.nsolved, w.ratio};
+        SD_HIP(sd::launch_ellip(s, ea));
+    }
     if (ev) SD_HIP(hipEventRecord(ev[2], s));
 #ifdef SD_WAVECLOCK
     double *gdbg = nullptr;                                // the debug buffer holds wavefront clocks in this build

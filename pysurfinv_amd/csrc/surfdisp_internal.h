@@ -49,6 +49,10 @@ struct PhaseArgs {
     // msrc[b * ms_b + f * ms_f + i * ms_i] - the SoA copy (1, Lmax * B, B) or the rows (9 * Lmax, Lmax, 1)
     const float *msrc;
     long ms_b, ms_f, ms_i;
+    // nullptr, or [P][B]: per solved period the state the ellipticity kernel replays the working stack from - (number of
+    // layers the period's rebuild refreshed) | (frozen effective half space << 16); -1: this period's ellipticity was
+    // computed in the kernel itself (exact fallback)
+    int *hist;
 #ifdef SD_WAVECLOCK
     unsigned long long *wclk;   // developer build: [waves][2] s_memrealtime at wavefront start / end
 #endif
@@ -67,6 +71,18 @@ struct GroupArgs {
     float *kb, *ka, *kr;  // nullptr, or [B][P][Lmax] analytic partials dc/dVs, dc/dVp, dc/drho
     float *kscr;          // nullptr, or the layer-major scratch [3][Lmax][P][B] they are accumulated in (coalesced)
 };
+
+struct EllipArgs {
+    int B, Lmax, P;
+    const float *mdl;     // SoA staged fields
+    const int *nl;
+    const float *per;
+    const float *c;       // [P][B] roots
+    const int *hist;      // [P][B], see PhaseArgs
+    const int *nsolved;   // [B]
+    float *ratio;         // [P][B]
+};
+hipError_t launch_ellip(hipStream_t s, const EllipArgs &a);
 
 struct FinishArgs {
     int B, P;

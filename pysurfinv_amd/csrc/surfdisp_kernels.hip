@@ -355,145 +355,118 @@ __device__ __forceinline__ void sincos_cw(float x, float *sn, float *cs)
 // and c is the same), and the half-space row is applied to rhoc h.  ~40 operations per layer instead of ~100.
 // Vertical wavenumbers ra, rb and their reciprocals come from ONE v_rsq_f32 each; sinh/cosh from two v_exp_f32.
 // (The reference's own arithmetic, statement by statement, is delta_rayleigh_ref below: the exact fallback kernel.)
-template <bool PIPE2 = true>
-__device__ __forceinline__ float delta_rayleigh(const float *wq, const int LS, const int S,
-                                                const int mmax, const float c, const float T,
-                                                const int start, float &phi)
+// One trial velocity's constants, the carried state and a layer's five values (rat: rho(m-1)/rho(m), formed when the
+// working stack is built).  ray_step / ray_close are shared by the root search (delta_rayleigh: layer values from the LDS
+// working stack) and by the ellipticity kernel (surfdisp_ellip_kernel: layer values rebuilt in registers) - the same
+// expressions, so a (c, stack state) pair gives the same value whichever kernel evaluates it.
+struct RTrial { float wvno, csq, icsq; };
+struct RState { float b1, h2, h3, h4, h5; };
+struct RLyr { float sv, d, ia2, ib2, rat; };
+__device__ __forceinline__ RTrial ray_trial(const float c, const float T)
 {
-    // phi: vertical phase sum_i k d_i sqrt(c^2/v_i^2 - 1) over the layers (and wave types) that are oscillatory
-    // at c -- the WKB mode counter the opt-in fast scan bounds between two coarse points (free: pm and qm are
-    // the recursion's own arguments)
-    phi = 0.0f;
-    const float wvno = 6.28318531f * rcp_nr(c * T);                 // <= 1 ulp: like a 6e-8 change of the period
-    const float csq = c * c;
-    const float icsq = rcp_nr(csq);
-    // start vector (1,0,0,0,0) / e2 / e3 in the scale of the top layer
-    const float irhoc0 = (start == 1) ? 0.0f : W_IR(0) * icsq;
-    float b1 = (start == 1) ? 1.0f : 0.0f, h2 = (start == 2) ? irhoc0 : 0.0f,
-          h3 = (start == 3) ? irhoc0 : 0.0f, h4 = 0.0f, h5 = 0.0f;
-    // software pipeline: layer m+1's six LDS values are in flight while layer m is computed.  The loop
-    // is unrolled by two over alternating register sets (no rotation moves between iterations).
-    struct Lyr { float sv, d, ia2, ib2, rat; };        // rat: rho(m-1)/rho(m), formed when the working stack is built
-    auto load = [&](int m) -> Lyr { return {W_B(m), W_D(m), W_IA2(m), W_IB2(m), W_IR(m)}; };
-    // first_tag: only the TOP layer may be liquid in the production kernel (a stack with a liquid layer further down
-    // is handed to the exact fallback kernel by the prep kernel's statistics), so the test is made once per evaluation
-    auto step = [&](const Lyr &y, auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const float sv = y.sv, d = y.d, ia2 = y.ia2, ib2 = y.ib2;
-        if (!FIRST) {                                      // into this layer's scale: rhoc_prev / rhoc = rho_prev / rho
-            const float rat = y.rat;
-            h2 *= rat; h3 *= rat; h4 *= rat; h5 *= rat * rat;
-        }
-        const float arga = fmaf(-csq, ia2, 1.0f);                    // 1 - c^2/a^2, surfa.f:211
-        // |arga| is clamped away from zero: c == a to the last bit then runs through the oscillatory formulas with
-        // ra = 1e-15, which give the reference's degenerate values (rsinp = 0, sinpr = k d, cosp = 1; surfa.f:263-266)
-        // to 1e-15 - no separate branch
-        const float xa = fmaxf(fabsf(arga), 1.0e-30f), ya = __builtin_amdgcn_rsqf(xa);
-        const float ra = copysignf(xa * ya, -arga), ira = copysignf(ya, -arga);   // ra = x rsq(x) to ~1.5 ulp; < 0: evanescent
-        const float wd = wvno * d;
-        if (FIRST && !(fabsf(sv) > ACCUR)) {
-            // liquid surface layer, surfa.f:216-251 (skipped entirely in the ellipticity passes): only a11 = cosp and
-            // a21 = rhoc sinpr are non-zero (surfa.f:236-250)
-            if (start != 1) return;
-            const float pm = wd * ra;
-            float sinpr, cosp;
-            if (fabsf(ra) < ACCUR) { sinpr = wd; cosp = 1.0f; }
-            else if (ra < 0.0f) {
-                float sh, ch; sinhcosh_sp(pm, &sh, &ch);
-                sinpr = sh / ra;
-                cosp = ch;
-            } else {
-                float sn, cs; sincos_cw(pm, &sn, &cs);
-                sinpr = sn / ra; cosp = cs;
-                phi += pm;
-            }
-            const float n1 = cosp * b1;
-            const float n2 = sinpr * b1;
-            const float n5 = cosp * h5 - sinpr * h4;
-            b1 = n1; h2 = n2; h3 = 0.0f; h4 = 0.0f; h5 = n5;
-            return;
-        }
-        const float argb = fmaf(-csq, ib2, 1.0f);
-        const float xb = fmaxf(fabsf(argb), 1.0e-30f), yb = __builtin_amdgcn_rsqf(xb);    // same for c == b (surfa.f:275-279)
-        const float rb = copysignf(xb * yb, -argb), irb = copysignf(yb, -argb);
-        const float g = 2.0f * (sv * sv) * icsq;
-        const float g1 = g - 1.0f;
+    RTrial t;
+    t.wvno = 6.28318531f * rcp_nr(c * T);                 // <= 1 ulp: like a 6e-8 change of the period
+    t.csq = c * c;
+    t.icsq = rcp_nr(t.csq);
+    return t;
+}
+// start vector (1,0,0,0,0) / e2 / e3 in the scale of the top layer (irho0 = 1 / rho of layer 0)
+__device__ __forceinline__ RState ray_start(const RTrial &t, const int start, const float irho0)
+{
+    const float irhoc0 = (start == 1) ? 0.0f : irho0 * t.icsq;
+    return RState{(start == 1) ? 1.0f : 0.0f, (start == 2) ? irhoc0 : 0.0f, (start == 3) ? irhoc0 : 0.0f, 0.0f, 0.0f};
+}
+// FIRST: only the TOP layer may be liquid in the production kernel (a stack with a liquid layer further down is handed
+// to the exact fallback kernel by the prep kernel's statistics), so the test is made once per evaluation
+template <bool FIRST>
+__device__ __forceinline__ void ray_step(RState &s, const RTrial &t, const RLyr &y, const int start, float &phi)
+{
+    float b1 = s.b1, h2 = s.h2, h3 = s.h3, h4 = s.h4, h5 = s.h5;
+    const float wvno = t.wvno, csq = t.csq, icsq = t.icsq;
+    const float sv = y.sv, d = y.d, ia2 = y.ia2, ib2 = y.ib2;
+    if (!FIRST) {                                      // into this layer's scale: rhoc_prev / rhoc = rho_prev / rho
+        const float rat = y.rat;
+        h2 *= rat; h3 *= rat; h4 *= rat; h5 *= rat * rat;
+    }
+    const float arga = fmaf(-csq, ia2, 1.0f);                    // 1 - c^2/a^2, surfa.f:211
+    // |arga| is clamped away from zero: c == a to the last bit then runs through the oscillatory formulas with
+    // ra = 1e-15, which give the reference's degenerate values (rsinp = 0, sinpr = k d, cosp = 1; surfa.f:263-266)
+    // to 1e-15 - no separate branch
+    const float xa = fmaxf(fabsf(arga), 1.0e-30f), ya = __builtin_amdgcn_rsqf(xa);
+    const float ra = copysignf(xa * ya, -arga), ira = copysignf(ya, -arga);   // ra = x rsq(x) to ~1.5 ulp; < 0: evanescent
+    const float wd = wvno * d;
+    if (FIRST && !(fabsf(sv) > ACCUR)) {
+        // liquid surface layer, surfa.f:216-251 (skipped entirely in the ellipticity passes): only a11 = cosp and
+        // a21 = rhoc sinpr are non-zero (surfa.f:236-250)
+        if (start != 1) return;
         const float pm = wd * ra;
-        const float qm = wd * rb;
-        float rsinp, sinpr, cosp, rsinq, sinqr, cosq;
-        if (arga > 0.0f) {                                 // evanescent P (ra < 0), surfa.f:267-269
+        float sinpr, cosp;
+        if (fabsf(ra) < ACCUR) { sinpr = wd; cosp = 1.0f; }
+        else if (ra < 0.0f) {
             float sh, ch; sinhcosh_sp(pm, &sh, &ch);
-            rsinp = -ra * sh; sinpr = sh * ira; cosp = ch;
-        } else {                                           // oscillatory P, surfa.f:271-273
+            sinpr = sh / ra;
+            cosp = ch;
+        } else {
             float sn, cs; sincos_cw(pm, &sn, &cs);
-            rsinp = ra * sn; sinpr = sn * ira; cosp = cs;
+            sinpr = sn / ra; cosp = cs;
             phi += pm;
         }
-        if (!(argb > 0.0f)) {
-            float sn, cs; sincos_cw(qm, &sn, &cs);
-            rsinq = rb * sn; sinqr = sn * irb; cosq = cs;
-            phi += qm;
-        } else {
-            float sh, ch; sinhcosh_sp(qm, &sh, &ch);
-            rsinq = -rb * sh; sinqr = sh * irb; cosq = ch;
-        }
-        const float g2 = g * g, g12 = g1 * g1;
-        const float u1 = fmaf(g2, b1, fmaf(g + g, h3, -h5));
-        const float u2 = fmaf(g12, b1, fmaf(g1 + g1, h3, -h5));
-        const float D = fmaf(-cosp, cosq, 1.0f);
-        const float t1 = fmaf(rsinq, u1, cosq * h2);            // rsinq u1 + cosq h2
-        const float t2 = fmaf(sinqr, u2, -(cosq * h4));         // sinqr u2 - cosq h4
-        const float Cx = cosp * rsinq, Cy = cosp * sinqr;
-        const float E1 = fmaf(rsinp, t1, fmaf(-Cx, h4, D * u2));
-        const float E2 = fmaf(sinpr, t2, fmaf(Cy, h2, D * u1));
-        const float n1 = (b1 - E1) - E2;
-        const float n3 = fmaf(g, E1, fmaf(g1, E2, h3));
-        const float n5 = fmaf(g2, E1, fmaf(g12, E2, h5));
-        const float n2 = fmaf(cosp, t1, sinpr * fmaf(rsinq, h4, cosq * u2));
-        const float n4 = fmaf(rsinp, fmaf(sinqr, h2, -(cosq * u1)), -(cosp * t2));
-        b1 = n1; h2 = n2; h3 = n3; h4 = n4; h5 = n5;
-    };
-    const int last = mmax - 1;                                       // the half space
-    Lyr A = load(0);
-    int m = 0;
-    if (last >= 1) {                                                 // layer 0: the one that may be water
-        const Lyr Bq = load(1);
-        step(A, std::true_type{});
-        A = Bq;
-        m = 1;
+        const float n1 = cosp * b1;
+        const float n2 = sinpr * b1;
+        const float n5 = cosp * h5 - sinpr * h4;
+        s.b1 = n1; s.h2 = n2; s.h3 = 0.0f; s.h4 = 0.0f; s.h5 = n5;
+        return;
     }
-    if (PIPE2) {
-        while (m + 2 <= last) {
-            const Lyr Bq = load(m + 1);
-            step(A, std::false_type{});
-            A = load(m + 2);
-            step(Bq, std::false_type{});
-            m += 2;
-        }
+    const float argb = fmaf(-csq, ib2, 1.0f);
+    const float xb = fmaxf(fabsf(argb), 1.0e-30f), yb = __builtin_amdgcn_rsqf(xb);    // same for c == b (surfa.f:275-279)
+    const float rb = copysignf(xb * yb, -argb), irb = copysignf(yb, -argb);
+    const float g = 2.0f * (sv * sv) * icsq;
+    const float g1 = g - 1.0f;
+    const float pm = wd * ra;
+    const float qm = wd * rb;
+    float rsinp, sinpr, cosp, rsinq, sinqr, cosq;
+    if (arga > 0.0f) {                                 // evanescent P (ra < 0), surfa.f:267-269
+        float sh, ch; sinhcosh_sp(pm, &sh, &ch);
+        rsinp = -ra * sh; sinpr = sh * ira; cosp = ch;
+    } else {                                           // oscillatory P, surfa.f:271-273
+        float sn, cs; sincos_cw(pm, &sn, &cs);
+        rsinp = ra * sn; sinpr = sn * ira; cosp = cs;
+        phi += pm;
+    }
+    if (!(argb > 0.0f)) {
+        float sn, cs; sincos_cw(qm, &sn, &cs);
+        rsinq = rb * sn; sinqr = sn * irb; cosq = cs;
+        phi += qm;
     } else {
-        // (also the opt-in fast scan's instantiations: their extra scan state put teams of four at 133 VGPRs = three
-        // wavefronts per SIMD, 27 M solves/s with one batch in flight; single-buffered 122 = four, 36 M.)
-        // Teams of two lanes - what a caller with several batches in flight gets (SURFDISP_PIPELINED) - keep ONE register
-        // set in flight: their wavefronts share SIMDs with the group-velocity kernel's (168 VGPRs), and three of them
-        // fit beside one of those only while 3 x VGPRs + 168 <= 512 (101 this way; measured at 120: the three-batch
-        // headline drops 7 %, profiles/r02e/ab_experiments.txt)
-        while (m + 1 <= last) {
-            const Lyr Bq = load(m + 1);
-            step(A, std::false_type{});
-            A = Bq;
-            m += 1;
-        }
+        float sh, ch; sinhcosh_sp(qm, &sh, &ch);
+        rsinq = -rb * sh; sinqr = sh * irb; cosq = ch;
     }
-    if (m < last) {
-        const Lyr Bq = load(m + 1);
-        step(A, std::false_type{});
-        A = Bq;
-    }
-    // half-space closure, surfa.f:340-354, on (b1, rhoc h2..h4, rhoc^2 h5) with rhoc of the last layer gone through
-    // (a itself is not needed: every occurrence is a^2, available as 1/ia2)
-    const float sv = A.sv, ia2 = A.ia2;                              // A holds layer mmax-1 here
-    const float irho = rcp_nr(W_R(last));
-    const float rhoc = (last >= 1 ? W_R(last - 1) : 0.0f) * csq;     // the state is in the scale of the last layer stepped through
+    const float g2 = g * g, g12 = g1 * g1;
+    const float u1 = fmaf(g2, b1, fmaf(g + g, h3, -h5));
+    const float u2 = fmaf(g12, b1, fmaf(g1 + g1, h3, -h5));
+    const float D = fmaf(-cosp, cosq, 1.0f);
+    const float t1 = fmaf(rsinq, u1, cosq * h2);            // rsinq u1 + cosq h2
+    const float t2 = fmaf(sinqr, u2, -(cosq * h4));         // sinqr u2 - cosq h4
+    const float Cx = cosp * rsinq, Cy = cosp * sinqr;
+    const float E1 = fmaf(rsinp, t1, fmaf(-Cx, h4, D * u2));
+    const float E2 = fmaf(sinpr, t2, fmaf(Cy, h2, D * u1));
+    const float n1 = (b1 - E1) - E2;
+    const float n3 = fmaf(g, E1, fmaf(g1, E2, h3));
+    const float n5 = fmaf(g2, E1, fmaf(g12, E2, h5));
+    const float n2 = fmaf(cosp, t1, sinpr * fmaf(rsinq, h4, cosq * u2));
+    const float n4 = fmaf(rsinp, fmaf(sinqr, h2, -(cosq * u1)), -(cosp * t2));
+    s.b1 = n1; s.h2 = n2; s.h3 = n3; s.h4 = n4; s.h5 = n5;
+}
+// half-space closure, surfa.f:340-354, on (b1, rhoc h2..h4, rhoc^2 h5) with rhoc of the last layer gone through
+// (a itself is not needed: every occurrence is a^2, available as 1/ia2); A = the values of layer mmax - 1, rho_last its
+// density, rho_prev the density of layer mmax - 2 (0 when there is none: the state is in that layer's scale)
+__device__ __forceinline__ float ray_close(const RState &s, const RTrial &t, const RLyr &A, const float rho_last,
+                                           const float rho_prev, const int start)
+{
+    const float csq = t.csq, icsq = t.icsq;
+    const float sv = A.sv, ia2 = A.ia2;
+    const float irho = rcp_nr(rho_last);
+    const float rhoc = rho_prev * csq;
     const float arga = fmaf(-csq, ia2, 1.0f);
     float ra = sqrt_hw(fabsf(arga));
     if (arga > 0.0f) ra = -ra;
@@ -512,8 +485,62 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int LS, c
     const float h14 = rb * it12 * igra;
     const float h15 = rba * (irho * irho) * ia2 * icsq * ig;         // rba/(rho a)^2/c^2/g
     const float h12 = -ig * it12;
-    const float bb1 = h11 * b1 + rhoc * (h12 * h2 + 2.0f * h13 * h3 + h14 * h4 + rhoc * (h15 * h5));
+    const float bb1 = h11 * s.b1 + rhoc * (h12 * s.h2 + 2.0f * h13 * s.h3 + h14 * s.h4 + rhoc * (h15 * s.h5));
     return (start == 1) ? -bb1 : bb1;
+}
+
+template <bool PIPE2 = true>
+__device__ __forceinline__ float delta_rayleigh(const float *wq, const int LS, const int S,
+                                                const int mmax, const float c, const float T,
+                                                const int start, float &phi)
+{
+    // phi: vertical phase sum_i k d_i sqrt(c^2/v_i^2 - 1) over the layers (and wave types) that are oscillatory
+    // at c -- the WKB mode counter the opt-in fast scan bounds between two coarse points (free: pm and qm are
+    // the recursion's own arguments)
+    phi = 0.0f;
+    const RTrial t = ray_trial(c, T);
+    RState s = ray_start(t, start, (start == 1) ? 0.0f : W_IR(0));
+    // software pipeline: layer m+1's LDS values are in flight while layer m is computed.  The loop
+    // is unrolled by two over alternating register sets (no rotation moves between iterations).
+    auto load = [&](int m) -> RLyr { return {W_B(m), W_D(m), W_IA2(m), W_IB2(m), W_IR(m)}; };
+    const int last = mmax - 1;                                       // the half space
+    RLyr A = load(0);
+    int m = 0;
+    if (last >= 1) {                                                 // layer 0: the one that may be water
+        const RLyr Bq = load(1);
+        ray_step<true>(s, t, A, start, phi);
+        A = Bq;
+        m = 1;
+    }
+    if (PIPE2) {
+        while (m + 2 <= last) {
+            const RLyr Bq = load(m + 1);
+            ray_step<false>(s, t, A, start, phi);
+            A = load(m + 2);
+            ray_step<false>(s, t, Bq, start, phi);
+            m += 2;
+        }
+    } else {
+        // (also the opt-in fast scan's instantiations: their extra scan state put teams of four at 133 VGPRs = three
+        // wavefronts per SIMD, 27 M solves/s with one batch in flight; single-buffered 122 = four, 36 M.)
+        // Teams of two lanes - what a caller with several batches in flight gets (SURFDISP_PIPELINED) - keep ONE register
+        // set in flight: their wavefronts share SIMDs with the group-velocity kernel's (168 VGPRs), and three of them
+        // fit beside one of those only while 3 x VGPRs + 168 <= 512 (101 this way; measured at 120: the three-batch
+        // headline drops 7 %, profiles/r02e/ab_experiments.txt)
+        while (m + 1 <= last) {
+            const RLyr Bq = load(m + 1);
+            ray_step<false>(s, t, A, start, phi);
+            A = Bq;
+            m += 1;
+        }
+    }
+    if (m < last) {
+        const RLyr Bq = load(m + 1);
+        ray_step<false>(s, t, A, start, phi);
+        A = Bq;
+    }
+    // A holds layer mmax-1 here; the state is in the scale of the last layer stepped through
+    return ray_close(s, t, A, W_R(last), last >= 1 ? W_R(last - 1) : 0.0f, start);
 }
 
 // The exact fallback kernel's Rayleigh secular function: DLTAR4 restated statement by statement (surfa.f:193-357),
@@ -798,6 +825,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
 
     // team-uniform state
     int k = k_own, nsolved = 0, mm_carry = n, mm_frozen = n, sub = 0, passes = 0;
+    int nflat_cur = n;                 // layers the current period's rebuild refreshed (recorded for the ellipticity kernel)
     float T = 1.0f, b1top = 0.0f;
     float p0c = 0.0f, p0d = 0.0f;      // "previous point" of lane 0: scan carry or bracket low end
     float cb = 0.0f, db = 0.0f;        // bracket high end (refine)
@@ -1345,6 +1373,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             if (j == 0) {
                 A.c[(size_t)k * B + b] = croot;                // period-major: coalesced across teams
                 if (want_ratio && !ell_pend) A.ratio[(size_t)k * B + b] = r12;
+                if (A.hist) A.hist[(size_t)k * B + b] = EXACT ? -1 : (nflat_cur | (mm_frozen << 16));
             }
             nsolved = ++k;
             if (INDEP || k >= P) { st = ST_DONE; }
@@ -1352,6 +1381,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 T = A.per[k];
                 mm_carry = mm_frozen;                          // mmax left by the last idrop=0 trial
                 build(mm_carry);
+                nflat_cur = mm_carry;
                 b1top = W_B(0);
                 p0c = 0.90f * croot;                           // calcul.f:143
                 p0d = 0.0f; p0mm = 0; p0ok = false; first = true; passes = 0;
@@ -1404,6 +1434,69 @@ template <int KIND, int G, bool INDEP, bool FAST = false, bool EXACT = false>
 __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArgs A)
 {
     phase_body<KIND, G, INDEP, FAST, EXACT>(A);
+}
+
+// ============================================================================= K1b: ellipticity
+// The Rayleigh ellipticity of every solved (stack, period): 0.5 bb1(e3) / bb1(e2), the two extra recursions of
+// DLTAR4(mup = 2) at the root (calcul.f:195, surfa.f:202-208,360-363), one lane per (stack, period) - full lanes, where the
+// root search could give them two lanes of a team riding in the next period's scan pass and a second LDS working stack to
+// read from (which cost deep stacks a workgroup per CU: 16 384 x L64, teams of 16: 51 KB -> 26 KB of LDS, three -> four
+// workgroups per CU = the launch's 4 096 wavefronts in ONE round).
+// The reference evaluates them on the working stack as phase 1 left it (COMMON /d/): only the first nflat layers are
+// refreshed per period, the layer nflat - 1 in half-space form, deeper ones keep an earlier period's values - and the
+// frozen mmax may reach into those.  The root search records (nflat, mmax) per solved period; this kernel replays the
+// history: layer i carries the values of the LAST period k' <= k whose rebuild covered it (k' falls monotonically as i
+// grows), with the same expressions the rebuild uses (layer_derive, rcp_nr), then steps both start vectors through
+// ray_step / ray_close - the root search's own functions.
+__global__ __launch_bounds__(256) void surfdisp_ellip_kernel(EllipArgs A)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int B = A.B, P = A.P;
+    if (idx >= (size_t)B * P) return;
+    const int b = (int)(idx % B), k = (int)(idx / B);       // a wavefront = 64 stacks, one period: coalesced SoA reads
+    const int n = A.nl[b];
+    if (n < 2 || k >= A.nsolved[b]) return;                 // (the finish kernel writes 0 for unsolved periods)
+    const int hk = A.hist[idx];
+    if (hk < 0) return;                                      // computed by the exact fallback kernel itself
+    const int mmf = hk >> 16;
+    const size_t fs = (size_t)A.Lmax * B;
+    const float c = A.c[idx], T = A.per[k];
+    const RTrial t = ray_trial(c, T);
+    int kk = k;                                              // period whose rebuild last refreshed the layer at hand
+    int nflat = hk & 0xffff;
+    float lnT = logf(1.0f / T);
+    RState s2{}, s3{};
+    float phi = 0.0f, rho_prev = 0.0f;
+    RLyr y{};
+    float rho_i = 0.0f;
+    const int last = mmf - 1;
+    for (int i = 0; i <= last; ++i) {
+        while (nflat <= i && kk > 0) {                       // an earlier rebuild: period 0 refreshed all n layers
+            --kk;
+            const int h = A.hist[(size_t)kk * B + b];
+            nflat = (h < 0) ? n : (h & 0xffff);
+            lnT = logf(1.0f / A.per[kk]);
+        }
+        const LayerV v = layer_derive(layer_load(A.mdl, fs, (size_t)i * B + b), lnT, i == nflat - 1);
+        rho_prev = rho_i;
+        rho_i = v.rho;
+        y.sv = v.b; y.d = v.d;
+        y.ia2 = rcp_nr(v.a * v.a);
+        y.ib2 = (v.b > 0.0f) ? rcp_nr(v.b * v.b) : 0.0f;
+        y.rat = (i > 0) ? rho_prev * rcp_nr(rho_i) : 0.0f;
+        if (i == 0) {
+            const float irho0 = rcp_nr(rho_i);
+            s2 = ray_start(t, 2, irho0);
+            s3 = ray_start(t, 3, irho0);
+            if (last >= 1) { ray_step<true>(s2, t, y, 2, phi); ray_step<true>(s3, t, y, 3, phi); }
+        } else if (i < last) {
+            ray_step<false>(s2, t, y, 2, phi);
+            ray_step<false>(s3, t, y, 3, phi);
+        }
+    }
+    const float rp = (last >= 1) ? rho_prev : 0.0f;
+    const float v2 = ray_close(s2, t, y, rho_i, rp, 2), v3 = ray_close(s3, t, y, rho_i, rp, 3);
+    A.ratio[idx] = 0.5f * v3 / v2;                           // surfa.f:363
 }
 
 // ================================================================================== K2: group
@@ -2237,6 +2330,13 @@ hipError_t launch_kern_transpose(hipStream_t s, const float *scr, float *out, in
 {
     const dim3 grid((unsigned)(P * ((B + 63) / 64)), (unsigned)((Lmax + 63) / 64));
     hipLaunchKernelGGL(surfdisp_kern_transpose_kernel, grid, dim3(256), 0, s, scr, out, B, P, Lmax);
+    return hipGetLastError();
+}
+
+hipError_t launch_ellip(hipStream_t s, const EllipArgs &a)
+{
+    const size_t total = (size_t)a.B * a.P;
+    hipLaunchKernelGGL(surfdisp_ellip_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
