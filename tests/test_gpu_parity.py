@@ -753,7 +753,8 @@ def _oracle_ratio(model, per, nlay=None):
     return c, u, r
 
 
-@pytest.mark.parametrize("case", ["synth_L10_R", "synth_L64_R", "water_L9_R", "two_layer_R", "synth_L21_R"])
+@pytest.mark.parametrize("case", ["synth_L10_R", "synth_L64_R", "water_L9_R", "two_layer_R", "synth_L21_R",
+                                  "rough_L10_R", "rough_L64_R", "rough_thick_L22_R"])
 def test_ellipticity_output_abi3(hip, ref_cases, case):
     """ABI 3 (surfdisp_forward_batch_device2): the Rayleigh ellipticity the reference computes and keeps in COMMON /o/
     ratio(k, 1) (calcul.f:195, surfa.f:360-363).  Checked against the reference itself where its shared object travelled
@@ -773,6 +774,7 @@ def test_ellipticity_output_abi3(hip, ref_cases, case):
     B, _, L = model.shape
     dm, dp = torch.from_numpy(model).cuda(), torch.from_numpy(per).cuda()
     plan = hip.BatchPlan(B, L, len(per))
+    strict_r = None
     for team in (0, 4, 16, 64):
         _lib.lib().surfdisp_set_team(team)
         for kind in (2, 2 | 0x10):
@@ -783,7 +785,23 @@ def test_ellipticity_output_abi3(hip, ref_cases, case):
             ok = co > 0
             assert np.array_equal(r[~ok], np.zeros_like(r[~ok]))   # unsolved periods: 0
             # (the ratio changes sign along the period list of a water-covered stack: absolute floor for the entries near zero)
-            assert (np.abs(r[ok] - ro[ok]) <= 1e-4 * np.abs(ro[ok]) + 3e-5).all(), (case, team, kind, np.abs(r[ok] - ro[ok]).max())
+            # rough stacks (low-velocity zones, stale deep layers: what the ellipticity kernel's replay of the working stack's
+            # history is for): held to 1e-3, except where the ratio is ill-conditioned in c - there the exact arithmetic on the
+            # same device (SURFDISP_STRICT, root 1e-7 away) moves it by more than the bar as well (rough_thick_L22_R stack 30,
+            # 3.3 s: oracle 0.648, strict 0.671, default 0.641 - and a group velocity within 2.4e-5 all the same)
+            rel = 1e-3 if case.startswith("rough") else 1e-4
+            okk = ok.copy()
+            for bb, kk in U_EXCEPTIONS.get(case, ()):              # the listed osculation entries: as for U
+                okk[bb, kk] = False
+            viol = np.where(okk, np.abs(r - ro) - (rel * np.abs(ro) + 3e-5), -1.0)
+            if case.startswith("rough") and (viol > 0).any():
+                if strict_r is None:
+                    strict_r = plan.run(dm, dp, kind=2, want_ratio=True, strict=True)[3].cpu().numpy().copy()
+                illc = np.abs(strict_r - ro) > 0.3 * (rel * np.abs(ro) + 3e-5)
+                assert (viol > 0).sum() <= 0.01 * okk.sum() and ((viol <= 0) | illc).all(), (case, team, kind, int((viol > 0).sum()))
+                continue
+            w = np.unravel_index(np.argmax(viol), viol.shape)
+            assert viol[w] <= 0, (case, team, kind, w, float(r[w]), float(ro[w]), float(c[w]), float(co[w]))
     _lib.lib().surfdisp_set_team(0)
     # Love: zeros
     c, u, st, r = plan.run(dm, dp, kind=1, want_ratio=True)
