@@ -215,8 +215,9 @@ def leg_roofline(leg, live_ms, alg_bytes_per_launch, kernel_prefix="surfdisp_pha
         return roof
     try:
         tj = json.load(open(tfile))
+        # the default instantiation <KIND, G, INDEP = 0, FAST = 0, EXACT = 0> with the team size this leg's launches use
         cands = {k: v for k, v in tj["kernels"].items() if k.startswith(kernel_prefix) and "valu_wave_instructions" in v
-                 and (team is None or k.split(",")[1] == str(team))}
+                 and k.endswith(",0,0,0>") and (team is None or k.split(",")[1] == str(team))}
         if not cands:
             roof["note"] = f"no {kernel_prefix}..> instantiation" + (f" with teams of {team}" if team else "") + " in the profile"
             return roof
@@ -410,12 +411,12 @@ def workload_grid(rt, args, steps=None, warmup=None):
     L = int(mb.to_model(state["p"][:4])[0].shape[2])
     acc_rate, = rt.max_over_ranks(float((track_row[:, 2] if fused else state["acc"].double()).mean()))
     per_rank_ms, = rt.max_over_ranks(elapsed / K * 1e3)
-    team = int(_lib.lib().surfdisp_get_team(C, L))         # (Rayleigh c+U sizing; phase-only calls may choose narrower)
+    team = int(_lib.lib().surfdisp_get_team2(C, L, len(MCMC_PERIODS), _lib.KIND_RAYLEIGH | _lib.PHASE_ONLY))
     return {"metric": "Metropolis steps/s, model3D grid share (BASELINE configs[3])", "unit": "steps/s",
             "ms_per_step_max_over_ranks": per_rank_ms,
             "kernel_ms": {"prep": kms[0], "phase": kms[1], "finish": kms[2],
                           "how": "HIP events on the launch stream around the solver's kernels of the K timed lock steps"},
-            "roofline": leg_roofline("grid", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * C),
+            "roofline": leg_roofline("grid", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * C, team=team),
             "value": rt.world * C * K / elapsed, "forward_solves_per_s": rt.world * C * K / elapsed,
             "ms_per_step": elapsed / K * 1e3, "steps": K, "warmup": W, "n_gpus": rt.world, "scaling": "weak",
             "config": {"workload": "BASELINE configs[3] share per GPU: 512 points x 50 chains, 96-layer continental model, "
@@ -437,7 +438,7 @@ def workload_mcmc(rt, args, steps=None, warmup=None):
            "config": {"workload": "BASELINE configs[2]: one point, 100 chains in lock step (100 000 steps = 1000 lock steps), "
                                   "96-layer continental model, 19 periods, Rayleigh phase-only misfit", "chains": 100}}
     mc = MetropolisBatch(mb.spec, mb.to_model, MCMC_PERIODS, c_obs[0], unc[0], device=rt.dev, seed=3 + rt.rank)
-    from pysurfinv_amd import forward
+    from pysurfinv_amd import _lib, forward
     mc.run(100, 4); rt.barrier()
     mc.event_ring = forward.EventRing(K)
     t0 = time.perf_counter(); mc.run(100, K + 1); rt.barrier()
@@ -447,7 +448,8 @@ def workload_mcmc(rt, args, steps=None, warmup=None):
     L = int(mb.to_model(mc.reset(2))[0].shape[2])
     out.update({"value": rt.world * 100 * K / dt, "ms_per_lock_step": dt / K * 1e3, "steps": K, "scaling": "weak",
                 "kernel_ms": {"prep": kms[0], "phase": kms[1], "finish": kms[2]},
-                "roofline": leg_roofline("mcmc", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * 100)})
+                "roofline": leg_roofline("mcmc", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * 100,
+                                         team=int(_lib.lib().surfdisp_get_team2(100, L, len(MCMC_PERIODS), _lib.KIND_RAYLEIGH | _lib.PHASE_ONLY)))})
     # the same lock step with the opt-in (stack, period) decomposition for small chain counts (independent="auto")
     mca = MetropolisBatch(mb.spec, mb.to_model, MCMC_PERIODS, c_obs[0], unc[0], device=rt.dev, seed=3 + rt.rank, independent="auto")
     mca.run(100, 4); rt.barrier()
@@ -474,7 +476,7 @@ def workload_c5(rt, args, steps=None, warmup=None):
     mantle: parameters -> stacks on the device), joint Rayleigh + Love phase + group velocity at 20 periods, and the
     analytic sensitivity kernels dc/d(Vs, Vp, rho) of every layer."""
     torch = rt.torch
-    from pysurfinv_amd import forward, senskernel, synth
+    from pysurfinv_amd import _lib, forward, senskernel, synth
     from pysurfinv_amd.brownian import TorchProposer
     from pysurfinv_amd.layers_batch import Model1DBatch
     B = int(os.environ.get("BENCH_C5_STACKS", "16384"))
@@ -515,8 +517,10 @@ def workload_c5(rt, args, steps=None, warmup=None):
                           "love": {"prep": kmsL[0], "phase": kmsL[1], "group_and_finish": kmsL[2]},
                           "how": "HIP events on each plan's own stream; the two streams share the chip, so a kernel's "
                                  "duration includes the time it shares SIMDs with the other wave type's kernels"},
-            "roofline": leg_roofline("c5", kmsR[1], (20 * L + 8 * 20) * B),
-            "roofline_love_root_search": leg_roofline("c5", kmsL[1], (20 * L + 8 * 20) * B, kernel_prefix="surfdisp_phase_kernel<1,")}
+            "roofline": leg_roofline("c5", kmsR[1], (20 * L + 8 * 20) * B,
+                                     team=int(_lib.lib().surfdisp_get_team2(B, L, 20, _lib.KIND_RAYLEIGH | _lib.PIPELINED))),
+            "roofline_love_root_search": leg_roofline("c5", kmsL[1], (20 * L + 8 * 20) * B, kernel_prefix="surfdisp_phase_kernel<1,",
+                                                      team=int(_lib.lib().surfdisp_get_team2(B, L, 20, _lib.KIND_LOVE | _lib.PIPELINED)))}
 
 
 def main():

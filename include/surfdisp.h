@@ -226,7 +226,8 @@ int surfdisp_workspace_fallback_count(void *stream, const void *workspace, int B
 /* lanes of one wavefront that cooperate on one stack's root search (1,2,4,...,64); 0 = choose
  * from (B, Lmax).  Also settable through the environment variable SURFDISP_TEAM. */
 int  surfdisp_set_team(int lanes);
-int  surfdisp_get_team(int B, int Lmax);           /* what a launch with (B, Lmax) would use */
+int  surfdisp_get_team(int B, int Lmax);           /* what a Rayleigh c+U launch with (B, Lmax) would use */
+int  surfdisp_get_team2(int B, int Lmax, int P, int kind);   /* ... a launch with these kind flags (wave type, PHASE_ONLY, PIPELINED, INDEPENDENT) */
 int  surfdisp_device_count(void);                  /* gfx950 devices visible; <=0: none */
 int  surfdisp_abi_version(void);
 const char *surfdisp_last_error(void);             /* thread-local, never NULL */

@@ -31,7 +31,7 @@ EXPORTS = (
     "surfdisp_events_elapsed_ms", "surfdisp_stream_wait_event", "surfdisp_params_to_model_device",
     "surfdisp_params_to_model_thermal_device", "surfdisp_thermal_scratch_bytes",
     "surfdisp_mcmc_propose_device", "surfdisp_mcmc_accept_device",
-    "surfdisp_forward_kernels_device", "surfdisp_kernels_workspace_bytes", "surfdisp_workspace_fallback_count", "surfdisp_set_team", "surfdisp_get_team",
+    "surfdisp_forward_kernels_device", "surfdisp_kernels_workspace_bytes", "surfdisp_workspace_fallback_count", "surfdisp_set_team", "surfdisp_get_team", "surfdisp_get_team2",
     "surfdisp_device_count", "surfdisp_abi_version", "surfdisp_last_error",
     "surfdisp_kernel_name",
 )
@@ -120,6 +120,8 @@ def lib() -> ctypes.CDLL:
     L.surfdisp_set_team.argtypes = [ctypes.c_int]
     L.surfdisp_get_team.restype = ctypes.c_int
     L.surfdisp_get_team.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.surfdisp_get_team2.restype = ctypes.c_int
+    L.surfdisp_get_team2.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.surfdisp_device_count.restype = ctypes.c_int
     L.surfdisp_abi_version.restype = ctypes.c_int
     L.surfdisp_last_error.restype = ctypes.c_char_p

@@ -195,6 +195,19 @@ int surfdisp_set_team(int lanes)
 
 int surfdisp_get_team(int B, int Lmax) { return pick_team(B, Lmax); }
 
+// lanes per stack a launch with these flags would use (kind: 1 | 2 with SURFDISP_PHASE_ONLY / _PIPELINED / _INDEPENDENT
+// OR'd in; P: periods, used by the independent decomposition) - what forward_device_impl computes
+int surfdisp_get_team2(int B, int Lmax, int P, int kind)
+{
+    const bool phase_only = (kind & SURFDISP_PHASE_ONLY) != 0, indep = (kind & SURFDISP_INDEPENDENT) != 0;
+    const bool pipelined = (kind & SURFDISP_PIPELINED) != 0, strict = (kind & SURFDISP_STRICT) != 0;
+    const int wave = kind & ~SD_KIND_FLAGS;
+    const bool want_ell = (wave == SURFDISP_KIND_RAYLEIGH) && !phase_only;
+    const long units = (indep ? (long)B * (P > 0 ? P : 1) : (long)B) * ((pipelined && wave != SURFDISP_KIND_LOVE) ? 2 : 1);
+    const bool ell_k_ok = want_ell && knobs().ell_kernel != 0 && !strict;
+    return pick_team((int)(units > 0x3fffffff ? 0x3fffffff : units), Lmax, want_ell && !ell_k_ok, pipelined, wave);
+}
+
 // developer hook (not in include/surfdisp.h): device buffer of B*P*16 doubles receiving
 // group-velocity intermediates of the next launches; nullptr switches it off.
 void surfdisp_debug_buffer(double *dev) { g_dbg.store(dev, std::memory_order_relaxed); }
