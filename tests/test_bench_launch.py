@@ -41,3 +41,28 @@ def test_failing_children_exit_nonzero():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "launchcheck"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_on_one_gpu_goes_through_the_launcher():
+    """`python bench.py --gpus 2 --workload grid` with no launcher around it, on a one-GPU box: BENCH_REHEARSAL=1 lets
+    both ranks share cuda:0 and rendezvous over gloo.  The parent launches, the ranks run the grid leg (a small share),
+    rank 0 prints the configs[3] line with the group's rank count, whole-job steps/s and the MAX-over-ranks step time."""
+    env = dict(os.environ, BENCH_REHEARSAL="1", BENCH_GRID_POINTS="64", BENCH_GRID_CHAINS="8")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "grid", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "torch imported in the launcher: False" in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["collective_backend"] == "gloo"
+    assert d["scaling"] == "weak" and d["unit"] == "steps/s" and d["config"]["chains_per_gpu"] == 512
+    assert d["value"] > 0 and abs(d["value"] - 2 * 512 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+    assert d["ms_per_step_max_over_ranks"] >= d["ms_per_step"] * 0.999
+    assert d["roofline"]["live_kernel_ms"] > 0
