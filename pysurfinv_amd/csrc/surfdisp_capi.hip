@@ -29,7 +29,11 @@ struct EnvKnobs {
     int device = 0;               // SURFDISP_DEVICE (fast_surf_)
     int balance = -1;             // SURFDISP_BALANCE (developer knob): wavefront priority by progress, -1 = automatic
     int rows_min_team = 8;        // SURFDISP_ROWS_MIN_TEAM (developer knob): teams of at least this many lanes rebuild from the row copy
-    int ell_kernel = 1;           // SURFDISP_ELL_KERNEL (developer knob): 0 = the ellipticity recursions inside the root search (r02)
+#ifdef SD_ELL_INKERNEL_WIDE
+    int ell_kernel = 0;           // A/B build: the ellipticity recursions inside the root search for every team size (r02)
+#else
+    int ell_kernel = 1;           // the ellipticity kernel for teams of >= 4 lanes
+#endif
     EnvKnobs()
     {
         if (const char *e = getenv("SURFDISP_TEAM")) team = atoi(e);
@@ -43,7 +47,6 @@ struct EnvKnobs {
         if (const char *e = getenv("SURFDISP_DEVICE")) device = atoi(e);
         if (const char *e = getenv("SURFDISP_BALANCE")) balance = atoi(e);
         if (const char *e = getenv("SURFDISP_ROWS_MIN_TEAM")) rows_min_team = atoi(e);
-        if (const char *e = getenv("SURFDISP_ELL_KERNEL")) ell_kernel = atoi(e);
     }
 };
 const EnvKnobs &knobs() { static const EnvKnobs k; return k; }

@@ -810,8 +810,18 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     // the main slot already holds period k+1 (only for teams of >= 4 lanes, see OVERLAP below)
     // the ellipticity (two more recursions per period, surfa.f:360-363) only feeds the group-velocity
     // kernel: a phase-only call (A.ratio == nullptr) skips it altogether
+    // Production teams of >= 4 lanes never compute them: surfdisp_ellip_kernel does (one lane per (stack, period)), and
+    // their instantiations carry no ellipticity state at all.  In-kernel: the exact fallback and two-lane teams (an
+    // ellipticity pass with both lanes busy).  -DSD_ELL_INKERNEL_WIDE restores the r02 arrangement for A/B builds (two
+    // lanes of a wide team riding in the next period's first scan pass, reading a snapshot in a second LDS slot).
+#ifdef SD_ELL_INKERNEL_WIDE
     const bool want_ratio = (KIND == 2) && (A.ratio != nullptr);
     const bool OVERLAP = !EXACT && want_ratio && (G >= 4) && !INDEP && (A.overlap != 0);
+#else
+    constexpr bool ELL_HERE = EXACT || (G < 4);
+    const bool want_ratio = ELL_HERE && (KIND == 2) && (A.ratio != nullptr);
+    constexpr bool OVERLAP = false;
+#endif
     float *wq2 = w_lds + (size_t)LS * Lcap + slot;
     // NEVILL's interpolation table x(1..11), y(1..11) (surfa.f:8) of this team, behind the working stacks
     float *nvx = w_lds + (size_t)((!EXACT && G >= 4 && A.overlap != 0) ? 2 : 1) * LS * Lcap + (size_t)slot * 24, *nvy = nvx + 12;
