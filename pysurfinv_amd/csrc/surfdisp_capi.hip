@@ -124,11 +124,11 @@ int pick_team(int B, int Lmax, bool need_ratio = true, bool pipelined = false, i
     int p2 = 1;
     while (p2 * 2 <= G) p2 *= 2;
     G = p2;
-    // The working stacks of a workgroup's 256/G teams (two slots each where the ellipticity passes ride in the next
-    // period's scan, Rayleigh c+U with teams of >= 4 lanes) are what limits the workgroups per CU: keep them within
-    // 44 KB per 256 lanes, i.e. at least three workgroups = wavefronts per SIMD, normally four - a wider team
-    // wastes fewer evaluations than a half-empty SIMD costs (scripts/sweep_team.py, profiles/r02e/sweep_team.txt:
-    // up to 1.5 x on batches of 30-64-layer stacks against the r02d budgets of 64 / 80 KB).
+    // The working stacks of a workgroup's 256/G teams are what limits the workgroups per CU (one slot each: since r03 the
+    // ellipticities of teams of >= 4 lanes come from their own kernel; need_ratio only sizes the second slot of an A/B build
+    // with -DSD_ELL_INKERNEL_WIDE): keep them within 44 KB per 256 lanes, i.e. at least three workgroups = wavefronts per
+    // SIMD, normally four - a wider team wastes fewer evaluations than a half-empty SIMD costs (scripts/sweep_team.py,
+    // profiles/r02e/sweep_team.txt; re-checked on the r03 kernels, every auto choice within 1 % of the best forced size).
     const size_t per256 = 256 / SD_PHASE_BLOCK;        // the budget is per 256 lanes
     // (a caller that keeps another batch in flight - SURFDISP_PIPELINED, the joint Rayleigh + Love plan - has the other
     // stream's wavefronts to fill a SIMD: there the narrower team's fewer evaluations win, 64 KB = two workgroups)
@@ -138,9 +138,9 @@ int pick_team(int B, int Lmax, bool need_ratio = true, bool pipelined = false, i
     return G;
 }
 
-// The second LDS slot (ellipticity of period k evaluated inside the first scan pass of period k+1) saves
-// one pass per period but doubles the workgroup's LDS (measured: on at 49 KB is 7-19 % faster than off, on at
-// 74 KB / 147 KB is 9 % / 38 % slower): on whenever the two slots fit - pick_team sized the team for that.
+// A/B builds with -DSD_ELL_INKERNEL_WIDE only (the r02 arrangement): the second LDS slot (ellipticity of period k
+// evaluated inside the first scan pass of period k+1) saves one pass per period but doubles the workgroup's LDS
+// (measured in r02: on at 49 KB is 7-19 % faster than off, on at 74 KB / 147 KB is 9 % / 38 % slower).
 static bool use_overlap(int Lmax, int G)
 {
     const size_t cap = knobs().overlap_max;
