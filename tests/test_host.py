@@ -100,3 +100,20 @@ def test_sediment_family_is_monotone_and_deterministic():
         assert np.all(m[:, 0, :] > 0) and np.all(m[:, 2, :] > 0) and np.all(m[:, 3, :] >= 0)
         assert np.all(m[:, 1, 1] < 3.0)                             # soft on top of the rock stack
         assert np.array_equal(m, synth.sediment_models(256, 14, seed=7, **kw))
+
+
+def test_team_introspection_needs_no_device():
+    """surfdisp_get_team / surfdisp_get_team2 are host logic (the sizing forward_device_impl applies): powers of two in
+    1..64, wider for fewer stacks, Love never below 8 lanes, a phase-only Rayleigh launch of the grid leg's share at 16."""
+    from pysurfinv_amd import _lib
+    L = _lib.lib()
+    R, LV, PH, PIPE, IND = _lib.KIND_RAYLEIGH, _lib.KIND_LOVE, _lib.PHASE_ONLY, _lib.PIPELINED, _lib.INDEPENDENT
+    for B, Lmax in ((1, 10), (100, 96), (4096, 20), (65536, 10), (25600, 96), (16384, 64)):
+        for kind in (R, R | PH, LV, R | PIPE, LV | PIPE, R | PH | IND):
+            g = L.surfdisp_get_team2(B, Lmax, 20, kind)
+            assert g in (1, 2, 4, 8, 16, 32, 64), (B, Lmax, kind, g)
+    assert L.surfdisp_get_team2(1, 10, 20, R) == 64 and L.surfdisp_get_team2(65536, 10, 20, R) == 4
+    assert L.surfdisp_get_team2(65536, 10, 20, R | PIPE) == 2           # three batches in flight: two-lane teams
+    assert L.surfdisp_get_team2(25600, 96, 19, R | PH) == 16            # the grid leg (LDS: 8-lane teams would need 74 KB)
+    assert L.surfdisp_get_team2(65536, 10, 20, LV) == 8 and L.surfdisp_get_team2(16384, 64, 20, LV | PIPE) == 16
+    assert L.surfdisp_get_team2(100, 96, 19, R | PH | IND) <= L.surfdisp_get_team2(100, 96, 19, R | PH)
