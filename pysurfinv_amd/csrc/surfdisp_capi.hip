@@ -28,6 +28,7 @@ struct EnvKnobs {
     bool fastscan = false;        // SURFDISP_FASTSCAN=1: opt every call of the process into the heuristic scan
     int device = 0;               // SURFDISP_DEVICE (fast_surf_)
     int balance = -1;             // SURFDISP_BALANCE (developer knob): wavefront priority by progress, -1 = automatic
+    int lockstep = -1;            // SURFDISP_LOCKSTEP (developer knob): -1 = automatic (on), 0 / 1, 2 = also for (stack, period) units
     int rows_min_team = 8;        // SURFDISP_ROWS_MIN_TEAM (developer knob): teams of at least this many lanes rebuild from the row copy
 #ifdef SD_ELL_INKERNEL_WIDE
     int ell_kernel = 0;           // A/B build: the ellipticity recursions inside the root search for every team size (r02)
@@ -47,6 +48,7 @@ struct EnvKnobs {
         if (const char *e = getenv("SURFDISP_DEVICE")) device = atoi(e);
         if (const char *e = getenv("SURFDISP_BALANCE")) balance = atoi(e);
         if (const char *e = getenv("SURFDISP_ROWS_MIN_TEAM")) rows_min_team = atoi(e);
+        if (const char *e = getenv("SURFDISP_LOCKSTEP")) lockstep = atoi(e);
     }
 };
 const EnvKnobs &knobs() { static const EnvKnobs k; return k; }
@@ -304,6 +306,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     if (use_rows) { ph.msrc = w.rows; ph.ms_b = 9L * Lmax; ph.ms_f = Lmax; ph.ms_i = 1; }
     else          { ph.msrc = w.mdl;  ph.ms_b = 1;         ph.ms_f = (long)Lmax * B; ph.ms_i = B; }
     ph.hist = ell_k ? w.hist : nullptr;
+    ph.lockstep = kn.lockstep >= 0 ? kn.lockstep : 1;
     SD_HIP(sd::launch_phase(s, kind, G, indep, ph));
     // the exact fallback re-solves what the production kernel listed (normally nothing: idle blocks exit at once)
     ph.overlap = 0; ph.fast = 0;

@@ -53,6 +53,7 @@ struct PhaseArgs {
     // layers the period's rebuild refreshed) | (frozen effective half space << 16); -1: this period's ellipticity was
     // computed in the kernel itself (exact fallback)
     int *hist;
+    int lockstep;         // the teams of a wavefront refine and end their periods together (see the root search's main loop)
 #ifdef SD_WAVECLOCK
     unsigned long long *wclk;   // developer build: [waves][2] s_memrealtime at wavefront start / end
 #endif

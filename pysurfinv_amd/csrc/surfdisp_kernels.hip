@@ -751,7 +751,9 @@ __device__ __forceinline__ int drop_layers(const float *wq, const int LS, const 
 }
 
 // ================================================================================== K1: phase
-enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3, ST_NEVILL = 4 };
+// ST_WREF / ST_WEND (lock step, see PhaseArgs::lockstep): a team that has its bracket / its root waits for the other teams
+// of its wavefront, so that the refine pass and the end-of-period block run ONCE per period for all of them
+enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3, ST_NEVILL = 4, ST_WREF = 5, ST_WEND = 6 };
 
 
 // INDEP = false: "faithful" - a team owns a stack and walks its periods in order (reference
@@ -954,6 +956,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     }
 
     int wprio = -1;
+    const bool LOCK = !EXACT && (INDEP ? A.lockstep >= 2 : A.lockstep != 0);
     while (__any(st != ST_DONE)) {
 #ifdef SD_WAVECLOCK
         const unsigned long long wp0 = __builtin_readcyclecounter();
@@ -977,7 +980,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         // ---------------------------------------------------------------- choose the trial point
         float cj = 1.0f;
         int mmj = 2, start = 1;
-        bool eval = (st != ST_DONE);
+        bool eval = (st != ST_DONE) && (st != ST_WREF) && (st != ST_WEND);
         const float *wl = wq;                                  // the stack this lane's recursion reads
         float Tl = T;
         const bool ell_lane = OVERLAP && ell_pend && (st == ST_SCAN) && (j < 2);
@@ -1033,7 +1036,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             const unsigned long long lead = __ballot(j == 0);
             wn_scan += __popcll(__ballot(st == ST_SCAN) & lead); wn_refine += __popcll(__ballot(st == ST_REFINE) & lead);
             wn_nevill += __popcll(__ballot(st == ST_NEVILL) & lead); wn_ellip += __popcll(__ballot(st == ST_ELLIP) & lead);
-            wn_idle += __popcll(__ballot(st == ST_DONE) & lead);
+            wn_idle += __popcll(__ballot(st == ST_DONE || st == ST_WREF || st == ST_WEND) & lead);
             int mx = eval ? mmj : 0, sm = eval ? mmj : 0;
             for (int d = 32; d > 0; d >>= 1) { mx = max(mx, __shfl_xor(mx, d)); sm += __shfl_xor(sm, d); }
             wtrip += mx; wlanelayers += sm; wlanes += __popcll(__ballot(eval));
@@ -1129,24 +1132,33 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         const int e_pmm = __shfl(pmm, src);
         const int l_mm = __shfl(mmj, tbase + G - 1);
         const int e_cross = __shfl((int)cross, src);
-        const int t_back0 = __shfl((int)back0, tbase);
+        const int t_back0 = fastok ? __shfl((int)back0, tbase) : 0;
         const int lastl = tbase + G - 1;
         const float l_c = __shfl(cj, lastl), l_d = __shfl(val, lastl);
         const float l_phi = fastok ? __shfl(phj, lastl) : 0.0f;
-        const float v0 = __shfl(val, tbase), v1 = __shfl(val, (G > 1) ? tbase + 1 : tbase);
-        const int nxt = (src < lastl) ? src + 1 : lastl;       // right neighbour of the crossing lane
-        const float e_nc = __shfl(cj, nxt), e_nd = __shfl(val, nxt);
-        const int pl = (G > 1) ? lastl - 1 : lastl;            // lane before the last one
-        const float pl_c = __shfl(cj, pl), pl_d = __shfl(val, pl);
-        const int pl_mm = __shfl(mmj, pl);
-        // two lanes below / above the crossing lane and two before the last one: the fourth point of REFINE's
-        // second three-point estimate
-        const int lm2s = (src - 2 >= tbase) ? src - 2 : tbase;
-        const float e_ppc = __shfl(cj, lm2s), e_ppd = __shfl(val, lm2s);
-        const int nx2 = (src + 2 <= lastl) ? src + 2 : lastl;
-        const float e_n2c = __shfl(cj, nx2), e_n2d = __shfl(val, nx2);
-        const int pl2 = (G > 2) ? lastl - 2 : lastl;
-        const float pl2_c = __shfl(cj, pl2), pl2_d = __shfl(val, pl2);
+        // the values of the team's first two lanes: the two ellipticity recursions, and NEVILL's del3 (every lane of the team
+        // evaluated the same c3) - only where some team of the wavefront needs them
+        float v0 = 0.0f, v1 = 0.0f;
+        if (__any(want_ratio || st == ST_NEVILL)) { v0 = __shfl(val, tbase); v1 = __shfl(val, (G > 1) ? tbase + 1 : tbase); }
+        // what only a REFINE pass reads (wavefront-uniform test: in lock step most passes have no refining team):
+        // the right neighbour of the crossing lane, the lane before the last one, and - the fourth point of the second
+        // three-point estimate - two lanes below / above the crossing lane and two before the last one
+        float e_nc = 0.0f, e_nd = 0.0f, pl_c = 0.0f, pl_d = 0.0f, e_ppc = 0.0f, e_ppd = 0.0f, e_n2c = 0.0f, e_n2d = 0.0f,
+              pl2_c = 0.0f, pl2_d = 0.0f;
+        int pl_mm = 0;
+        if (fastok || __any(st == ST_REFINE)) {
+            const int nxt = (src < lastl) ? src + 1 : lastl;
+            e_nc = __shfl(cj, nxt); e_nd = __shfl(val, nxt);
+            const int pl = (G > 1) ? lastl - 1 : lastl;
+            pl_c = __shfl(cj, pl); pl_d = __shfl(val, pl);
+            if (fastok) pl_mm = __shfl(mmj, pl);
+            const int lm2s = (src - 2 >= tbase) ? src - 2 : tbase;
+            e_ppc = __shfl(cj, lm2s); e_ppd = __shfl(val, lm2s);
+            const int nx2 = (src + 2 <= lastl) ? src + 2 : lastl;
+            e_n2c = __shfl(cj, nx2); e_n2d = __shfl(val, nx2);
+            const int pl2 = (G > 2) ? lastl - 2 : lastl;
+            pl2_c = __shfl(cj, pl2); pl2_d = __shfl(val, pl2);
+        }
         const bool had_ell = OVERLAP && ell_pend && (st == ST_SCAN);
 
         bool solved = false, failed = false;
@@ -1199,7 +1211,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 // and only its sign may be used (NEVILL's 10x guard, surfa.f:47-51, covers this)
                 p0ok = (e_pmm == e_mm);
                 passes = 0;
-                st = ST_REFINE;
+                st = LOCK ? ST_WREF : ST_REFINE;
                 if (EXACT) {                                   // NEVILL's prologue, surfa.f:12-16
                     nv_ic = 0; nv_nev = 1; nv_m = 1;
                     croot = (p0c + cb) / 2.0f;                 // c3, evaluated by the next pass
@@ -1376,6 +1388,22 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         if (fatal) {
             nsolved = 0; k = 0; status = SURFDISP_NUMERIC; st = ST_DONE; ell_pend = false; solved = false; failed = false;
         }
+        if (failed) {
+            status = (k == 0) ? SURFDISP_NOROOT : SURFDISP_PARTIAL;
+            st = ST_DONE;
+        }
+        if (LOCK) {
+            // Lock step of the teams of a wavefront: with many teams per wavefront (16 of four lanes) SOME team is at its
+            // refine pass or at the end of a period in nearly every pass, and the wavefront then runs those blocks for one
+            // team in sixteen - team decisions and end-of-period block were 35 % of a ten-layer wavefront's time.  Here a team
+            // with its bracket waits until no team of the wavefront scans any more, all refine together, and a team with its
+            // root waits until all have theirs: one refine pass and one end-of-period block per period and wavefront.  A
+            // waiting team evaluates nothing; each team's own sequence of evaluations - and so every result - is unchanged.
+            if (solved) { st = ST_WEND; solved = false; }
+            if (!__any(st == ST_SCAN) && st == ST_WREF) st = ST_REFINE;
+            if (!__any(st == ST_SCAN || st == ST_WREF || st == ST_REFINE || st == ST_NEVILL || st == ST_ELLIP) && st == ST_WEND)
+                solved = true;
+        }
 #ifdef SD_WAVECLOCK
         const unsigned long long wb0 = __builtin_readcyclecounter();
 #endif
@@ -1404,10 +1432,6 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
 #ifdef SD_WAVECLOCK
         wcyc_build += __builtin_readcyclecounter() - wb0;      // store of the root, next period's set-up, stack rebuild
 #endif
-        if (failed) {
-            status = (k == 0) ? SURFDISP_NOROOT : SURFDISP_PARTIAL;
-            st = ST_DONE;
-        }
     }
 #ifdef SD_WAVECLOCK
     if (!EXACT && A.wclk && (threadIdx.x & 63) == 0) {
