@@ -377,17 +377,28 @@ def workload_grid(rt, args, steps=None, warmup=None):
     fused = mc.fused_available() and os.environ.get("BENCH_GRID_FUSED", "1") == "1"
     track_row = torch.zeros((C, 3 + mb.spec.n), dtype=torch.float64, device=rt.dev)
 
+    # chain groups as the library forms them (MetropolisBatch.chain_groups: two from 4 096 chains on, each on its own
+    # stream; BENCH_GRID_GROUPS overrides) - the chains themselves do not depend on the grouping
+    genv = os.environ.get("BENCH_GRID_GROUPS")
+    cg = mc.chain_groups(C, int(genv) if genv else None) if fused else None
+
     def setup():
         state["p"] = mc.reset(C).contiguous()
-        if fused:
+        if cg is not None:
+            cg.fork()
+            cg.step(state["p"], first=True)
+        elif fused:
             mc.fused_step(state["p"], first=True)          # chi-square of the start models into the sampler's state
         else:
             state["chi"] = mc.misfit(state["p"])[1]
 
     def step_fused():
-        # the lock step as the library runs it (MetropolisBatch.run): propose kernel, parameters -> stacks, prep / root
-        # search / finish, accept kernel (misfit, accept rule, state update, mcTrack row)
-        mc.fused_step(state["p"], row=track_row, row_stride=3 + mb.spec.n)
+        # the step of every chain as the library runs it (MetropolisBatch.run): propose kernel, parameters -> stacks,
+        # prep / root search / finish, accept kernel (misfit, accept rule, state update, mcTrack row), per chain group
+        if cg is not None:
+            cg.step(state["p"], row=track_row, row_stride=3 + mb.spec.n)
+        else:
+            mc.fused_step(state["p"], row=track_row, row_stride=3 + mb.spec.n)
 
     def step():
         if fused:
@@ -404,25 +415,33 @@ def workload_grid(rt, args, steps=None, warmup=None):
     setup()
     n0 = mc.n_forward
     from pysurfinv_amd import _lib, forward
-    mc.event_ring = forward.EventRing(K)                   # HIP events on the launch stream around the solver's kernels
+    ring = forward.EventRing(K)                            # HIP events on the launch stream around the solver's kernels
+    emc = cg.children[0] if cg is not None else mc         # (chain groups: the first group's stream)
+    emc.event_ring = ring
     elapsed = rt.timed(step, K, W)
-    kms = mc.event_ring.kernel_ms().mean(axis=0)
-    mc.event_ring = None
+    kms = ring.kernel_ms().mean(axis=0)
+    emc.event_ring = None
+    if cg is not None:
+        cg.join()
     L = int(mb.to_model(state["p"][:4])[0].shape[2])
     acc_rate, = rt.max_over_ranks(float((track_row[:, 2] if fused else state["acc"].double()).mean()))
     per_rank_ms, = rt.max_over_ranks(elapsed / K * 1e3)
-    team = int(_lib.lib().surfdisp_get_team2(C, L, len(MCMC_PERIODS), _lib.KIND_RAYLEIGH | _lib.PHASE_ONLY))
+    Cl = (cg.bounds[1] - cg.bounds[0]) if cg is not None else C          # chains per launch (one chain group)
+    team = int(_lib.lib().surfdisp_get_team2(Cl, L, len(MCMC_PERIODS), _lib.KIND_RAYLEIGH | _lib.PHASE_ONLY))
     return {"metric": "Metropolis steps/s, model3D grid share (BASELINE configs[3])", "unit": "steps/s",
             "ms_per_step_max_over_ranks": per_rank_ms,
             "kernel_ms": {"prep": kms[0], "phase": kms[1], "finish": kms[2],
-                          "how": "HIP events on the launch stream around the solver's kernels of the K timed lock steps"},
-            "roofline": leg_roofline("grid", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * C, team=team),
+                          "how": "HIP events on the launch stream around the solver's kernels of the K timed lock steps"
+                                 + (f" (first of {cg.G} chain groups, {Cl} chains per launch; the groups' streams share the chip, so a "
+                                    "kernel's duration includes the time it shares SIMDs with the other group's kernels)" if cg is not None else "")},
+            "roofline": leg_roofline("grid", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * Cl, team=team),
             "value": rt.world * C * K / elapsed, "forward_solves_per_s": rt.world * C * K / elapsed,
             "ms_per_step": elapsed / K * 1e3, "steps": K, "warmup": W, "n_gpus": rt.world, "scaling": "weak",
             "config": {"workload": "BASELINE configs[3] share per GPU: 512 points x 50 chains, 96-layer continental model, "
                                    "19 periods, Rayleigh phase-only misfit, default scan",
                        "lock_step": ("fused: propose kernel, parameters->stacks, prep / root search / finish, accept kernel"
                                      if fused else "torch glue around the solver"),
+                       "chain_groups": cg.G if cg is not None else 1,
                        "points_per_gpu": pts, "chains_per_point": chains, "chains_per_gpu": C, "layers": L,
                        "periods": len(MCMC_PERIODS)},
             "accept_rate_last_step": acc_rate, "forward_solves_timed_this_rank": int(mc.n_forward - n0)}

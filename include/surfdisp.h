@@ -204,14 +204,17 @@ int surfdisp_params_to_model_thermal_device(void *stream, int C, int N, int L, c
  *            chi1 < chi0 or u > 1 - exp(-(chi1-chi0)/2) (point.py:34-37), p0 / chi0 updated in place, and the mcTrack row
  *            [misfit, L, accepted, *proposal] (models.py:254-256) written to row + chain * row_stride (doubles) if row.
  *            c_obs / uncer / mask are [P], or [C][P] with obs_per_chain.  first != 0: a chain's first row (accepted).
- *   Random numbers: Philox4x32-10 keyed by `seed`; the caller passes a fresh `counter` per call.  Device pointers,
- *   stream-ordered, no host synchronisation, graph-capturable. */
+ *   Random numbers: Philox4x32-10 keyed by `seed`; the caller passes a fresh `counter` per call.  chain0: the index, in
+ *   the whole sampler, of this call's chain 0 - the random streams are indexed by chain0 + c, so a sampler that advances
+ *   its chains in several groups (one call per group, e.g. on several streams) draws exactly what one call over all
+ *   chains draws.  Device pointers, stream-ordered, no host synchronisation, graph-capturable. */
 int surfdisp_mcmc_propose_device(void *stream, int C, int N, const double *p, const double *vmin, const double *vmax,
-                                 const double *step, unsigned long long seed, unsigned long long counter, int reset, double *out);
+                                 const double *step, unsigned long long seed, unsigned long long counter, int reset, double *out,
+                                 long chain0);
 int surfdisp_mcmc_accept_device(void *stream, int C, int N, int P, const float *c, const int *status,
                                 const double *c_obs, const double *uncer, const unsigned char *mask, int obs_per_chain,
                                 const double *p1, double *p0, double *chi0, double *row, long row_stride,
-                                unsigned long long seed, unsigned long long counter, int first);
+                                unsigned long long seed, unsigned long long counter, int first, long chain0);
 
 /* ---- (7) introspection of the two-tier root search.  The production kernel hands the stacks it cannot treat
  *          faithfully to an exact fallback kernel that runs right behind it inside the same call: a secular

@@ -110,10 +110,10 @@ def lib() -> ctypes.CDLL:
                                                           vp, ctypes.c_size_t, vp]
     u64 = ctypes.c_ulonglong
     L.surfdisp_mcmc_propose_device.restype = ctypes.c_int
-    L.surfdisp_mcmc_propose_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, u64, u64, ctypes.c_int, vp]
+    L.surfdisp_mcmc_propose_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, u64, u64, ctypes.c_int, vp, ctypes.c_long]
     L.surfdisp_mcmc_accept_device.restype = ctypes.c_int
     L.surfdisp_mcmc_accept_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int,
-                                              vp, vp, vp, vp, ctypes.c_long, u64, u64, ctypes.c_int]
+                                              vp, vp, vp, vp, ctypes.c_long, u64, u64, ctypes.c_int, ctypes.c_long]
     L.surfdisp_workspace_fallback_count.restype = ctypes.c_int
     L.surfdisp_workspace_fallback_count.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip]
     L.surfdisp_set_team.restype = ctypes.c_int

@@ -422,10 +422,10 @@ int surfdisp_params_to_model_thermal_device(void *stream, int C, int N, int L, c
 
 // Metropolis glue on the device (surfdisp_mcmc.hip): proposal and misfit / accept / state update of one lock step.
 int surfdisp_mcmc_propose_device(void *stream, int C, int N, const double *p, const double *vmin, const double *vmax,
-                                 const double *step, unsigned long long seed, unsigned long long counter, int reset, double *out)
+                                 const double *step, unsigned long long seed, unsigned long long counter, int reset, double *out, long chain0)
 {
-    if (C < 1 || N < 1 || !p || !vmin || !vmax || !step || !out) { set_err("surfdisp_mcmc_propose_device: bad argument"); return SURFDISP_ERR_INVALID; }
-    sd::McmcProposeArgs a{C, N, p, vmin, vmax, step, seed, counter, reset ? 1 : 0, out};
+    if (C < 1 || N < 1 || !p || !vmin || !vmax || !step || !out || chain0 < 0) { set_err("surfdisp_mcmc_propose_device: bad argument"); return SURFDISP_ERR_INVALID; }
+    sd::McmcProposeArgs a{C, N, p, vmin, vmax, step, seed, counter, reset ? 1 : 0, out, chain0};
     SD_HIP(sd::launch_mcmc_propose(static_cast<hipStream_t>(stream), a));
     return SURFDISP_SUCCESS;
 }
@@ -433,12 +433,12 @@ int surfdisp_mcmc_propose_device(void *stream, int C, int N, const double *p, co
 int surfdisp_mcmc_accept_device(void *stream, int C, int N, int P, const float *c, const int *status,
                                 const double *c_obs, const double *uncer, const unsigned char *mask, int obs_per_chain,
                                 const double *p1, double *p0, double *chi0, double *row, long row_stride,
-                                unsigned long long seed, unsigned long long counter, int first)
+                                unsigned long long seed, unsigned long long counter, int first, long chain0)
 {
     if (C < 1 || N < 1 || P < 1 || !c || !c_obs || !uncer || !mask || !p1 || !p0 || !chi0) {
         set_err("surfdisp_mcmc_accept_device: bad argument"); return SURFDISP_ERR_INVALID;
     }
-    sd::McmcAcceptArgs a{C, N, P, c, status, c_obs, uncer, mask, obs_per_chain ? 1 : 0, p1, p0, chi0, row, row_stride, seed, counter, first ? 1 : 0};
+    sd::McmcAcceptArgs a{C, N, P, c, status, c_obs, uncer, mask, obs_per_chain ? 1 : 0, p1, p0, chi0, row, row_stride, seed, counter, first ? 1 : 0, chain0};
     SD_HIP(sd::launch_mcmc_accept(static_cast<hipStream_t>(stream), a));
     return SURFDISP_SUCCESS;
 }

@@ -112,6 +112,7 @@ struct McmcProposeArgs {
     unsigned long long seed, counter;
     int reset;              // 1: uniform prior draw for every entry (MCinv.reset), 0: bounded Gaussian step
     double *out;            // [C][N]
+    long chain0;            // global index of chain 0 of this launch (keys the random streams: a sampler split into chain groups draws what the unsplit one draws)
 };
 struct McmcAcceptArgs {
     int C, N, P;
@@ -127,6 +128,7 @@ struct McmcAcceptArgs {
     long row_stride;        // in doubles
     unsigned long long seed, counter;
     int first;              // 1: first row of a chain (always accepted: the start model)
+    long chain0;            // global index of chain 0 of this launch
 };
 hipError_t launch_mcmc_propose(hipStream_t s, const McmcProposeArgs &a);
 hipError_t launch_mcmc_accept(hipStream_t s, const McmcAcceptArgs &a);

@@ -42,10 +42,11 @@ __global__ __launch_bounds__(256) void surfdisp_mcmc_propose_kernel(McmcProposeA
     const int n = (int)(idx % A.N);
     const double x = A.p[idx], lo = A.vmin[n], hi = A.vmax[n], s = A.step[n];
     const uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
+    const long gidx = idx + A.chain0 * A.N;                             // (chain, parameter) of the whole sampler: the random stream's index
     double nv = 0.0;
     bool ok = false;
     for (uint32_t t = 0; t < 500 && !ok; ++t) {                        // two normals per Philox call: 1000 tries
-        const U4 r = philox4x32_10(U4{(uint32_t)A.counter, (uint32_t)(A.counter >> 32) ^ (t << 8), (uint32_t)idx, (uint32_t)(idx >> 32)}, k0, k1);
+        const U4 r = philox4x32_10(U4{(uint32_t)A.counter, (uint32_t)(A.counter >> 32) ^ (t << 8), (uint32_t)gidx, (uint32_t)(gidx >> 32)}, k0, k1);
         const double u1 = u53(r.x, r.y), u2 = u53(r.z, r.w);
         const double rad = sqrt(-2.0 * log(u1));
         double sn, cs;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void surfdisp_mcmc_propose_kernel(McmcProposeA
         if (!ok) { nv = x + s * rad * sn; ok = (nv < hi) && (nv > lo); }
     }
     if (!ok || A.reset) {                                              // "No valid perturb, uniform reset instead!" / MCinv.reset
-        const U4 r = philox4x32_10(U4{(uint32_t)A.counter, (uint32_t)(A.counter >> 32) ^ 0x00ffff00u, (uint32_t)idx, (uint32_t)(idx >> 32)}, k0, k1);
+        const U4 r = philox4x32_10(U4{(uint32_t)A.counter, (uint32_t)(A.counter >> 32) ^ 0x00ffff00u, (uint32_t)gidx, (uint32_t)(gidx >> 32)}, k0, k1);
         nv = lo + (hi - lo) * u53(r.x, r.y);
     }
     A.out[idx] = nv;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void surfdisp_mcmc_accept_kernel(McmcAcceptArg
     if (A.first) acc = true;                                           // a chain's first row: the start model itself
     else if (chi < chi0) acc = true;                                   // point.py:34-37
     else {
-        const U4 r = philox4x32_10(U4{(uint32_t)A.counter, (uint32_t)(A.counter >> 32) ^ 0x00aaaa00u, (uint32_t)c, 0u}, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+        const U4 r = philox4x32_10(U4{(uint32_t)A.counter, (uint32_t)(A.counter >> 32) ^ 0x00aaaa00u, (uint32_t)(A.chain0 + c), (uint32_t)((unsigned long long)(A.chain0 + c) >> 32)}, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
         const double u = u53(r.x, r.y);
         acc = u > 1.0 - exp(-(chi - chi0) / 2.0);
     }

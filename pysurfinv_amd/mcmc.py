@@ -34,6 +34,61 @@ from .brownian import ParamSpec, TorchProposer
 FAIL = 88888.0                                                  # point.py:21
 
 
+class ChainGroups:
+    """The chains of a ``MetropolisBatch`` as contiguous groups, each advancing on its own stream (``chain_groups``).
+    ``fork()`` once (the group streams wait for the current stream), ``step()`` per lock step, ``join()`` once (the current
+    stream waits for every group): between the two nothing synchronises the groups with each other."""
+
+    def __init__(self, mc, C, G):
+        import copy
+        torch = mc.torch
+        self.mc, self.C, self.G = mc, int(C), int(G)
+        self.bounds = [self.C * g // self.G for g in range(self.G + 1)]
+        self.streams = [torch.cuda.Stream(device=mc.device) for _ in range(self.G)]
+        self.children = []
+        for g in range(self.G):
+            lo, hi = self.bounds[g], self.bounds[g + 1]
+            ch = copy.copy(mc)                                  # shares spec, proposer (bounds, steps, seed), periods, to_model
+            ch._plan, ch._fz, ch.event_ring, ch._ev_i, ch.n_forward, ch._groups = None, None, None, 0, 0, {}
+            if mc.c_obs.ndim == 2:
+                if mc.c_obs.shape[0] != self.C:
+                    raise ValueError(f"{self.C} chains against {mc.c_obs.shape[0]} rows of observations")
+                ch.c_obs, ch.uncer, ch.mask = mc.c_obs[lo:hi], mc.uncer[lo:hi], mc.mask[lo:hi]
+            if mc.local_rows is not None:
+                ch.local_rows = mc.local_rows[lo:hi]
+            ch._chain0 = mc._chain0 + lo
+            ch._pipelined = True                                # the library sizes its teams for both groups' stacks
+            self.children.append(ch)
+
+    def fork(self):
+        cur = self.mc.torch.cuda.current_stream(self.mc.device)
+        for s in self.streams:
+            s.wait_stream(cur)
+        self.children[0].event_ring, self.children[0]._ev_i = self.mc.event_ring, self.mc._ev_i    # bench.py's measurement hook
+
+    def step(self, p, row=None, row_stride=0, row_offset=0, first=False, counter=None):
+        """One Metropolis step of every chain: state ``p`` [C, N] in place, rows as ``MetropolisBatch.fused_step``."""
+        torch = self.mc.torch
+        if counter is None:
+            self.mc._counter += 1
+            counter = self.mc._counter
+        for g, ch in enumerate(self.children):
+            lo, hi = self.bounds[g], self.bounds[g + 1]
+            with torch.cuda.stream(self.streams[g]):
+                ch.fused_step(p[lo:hi], row=row, row_stride=row_stride, row_offset=row_offset + lo * row_stride,
+                              first=first, counter=counter)
+
+    def join(self):
+        cur = self.mc.torch.cuda.current_stream(self.mc.device)
+        for s in self.streams:
+            cur.wait_stream(s)
+        for ch in self.children:
+            self.mc.n_forward += ch.n_forward
+            ch.n_forward = 0
+        self.mc._ev_i = self.children[0]._ev_i
+        self.children[0].event_ring = None
+
+
 class MetropolisBatch:
     """C chains in lock step.
 
@@ -86,6 +141,10 @@ class MetropolisBatch:
         # measurement hook (bench.py): a forward.EventRing whose next slot brackets the solver's kernels of each call
         self.event_ring = None
         self._ev_i = 0
+        self._counter = 0                                       # calls of the fused kernels so far: the Philox counter of the next one
+        self._pipelined = False                                 # a chain group: another group's solve is in flight beside this one
+        self._chain0 = 0                                        # index of this object's chain 0 in the whole sampler (chain groups)
+        self._groups = {}
 
     # ------------------------------------------------------------------ forward + misfit
     def forward_c(self, params, rows=None):
@@ -143,8 +202,7 @@ class MetropolisBatch:
             N = self.spec.n
             st = dict(C=C, p1=torch.empty((C, N), dtype=torch.float64, device=self.device),
                       chi=torch.zeros(C, dtype=torch.float64, device=self.device),
-                      mask8=self.mask.to(torch.uint8).contiguous(), c_obs=self.c_obs.contiguous(), uncer=self.uncer.contiguous(),
-                      counter=0)
+                      mask8=self.mask.to(torch.uint8).contiguous(), c_obs=self.c_obs.contiguous(), uncer=self.uncer.contiguous())
             self._fz = st
         return st
 
@@ -168,14 +226,16 @@ class MetropolisBatch:
             self._ev_i += 1
         indep = (C < self.AUTO_INDEP_CHAINS) if self.independent == "auto" else bool(self.independent)
         c, _, st = self._plan.run(model.contiguous(), self.periods, kind=_lib.KIND_RAYLEIGH | _lib.PHASE_ONLY,
-                                  nlay=nlay, independent=indep, fast_scan=self.fast_scan, events=ev)
+                                  nlay=nlay, independent=indep, fast_scan=self.fast_scan, events=ev,
+                                  pipelined=self._pipelined)
         return c, st
 
-    def fused_step(self, p, row=None, row_stride=0, first=False):
+    def fused_step(self, p, row=None, row_stride=0, first=False, counter=None, row_offset=0):
         """One Metropolis step of every chain, in place on the state ``p`` [C, N] (float64, contiguous): proposal
         (``first``: none - the states themselves are evaluated and accepted, a chain's first row), stacks, forward solve,
-        misfit / accept / update.  ``row``: a float64 tensor whose element 0 is where chain 0's mcTrack row goes, chain c's
-        ``row_stride`` doubles further.  Everything stream-ordered on the current stream."""
+        misfit / accept / update.  ``row``: a float64 tensor whose element ``row_offset`` is where chain 0's mcTrack row
+        goes, chain c's ``row_stride`` doubles further.  ``counter``: the Philox counter of this step (default: one more
+        than the last call's).  Everything stream-ordered on the current stream."""
         import ctypes
         torch = self.torch
         C, N = p.shape
@@ -184,20 +244,50 @@ class MetropolisBatch:
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         ptr = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
         pr = self.proposer
-        st["counter"] += 1
+        if counter is None:
+            self._counter += 1
+            counter = self._counter
+        rowp = ctypes.c_void_p(row.data_ptr() + 8 * int(row_offset)) if row is not None else ctypes.c_void_p(0)
         with torch.cuda.device(self.device):
             if first:
                 p1 = p
             else:
                 p1 = st["p1"]
                 _lib.check(L.surfdisp_mcmc_propose_device(stream, C, N, ptr(p), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step),
-                                                          pr.seed_int, st["counter"], 0, ptr(p1)))
+                                                          pr.seed_int, counter, 0, ptr(p1), self._chain0))
             c, status = self._solve_raw(p1)
             _lib.check(L.surfdisp_mcmc_accept_device(stream, C, N, int(self.periods.numel()), ptr(c), ptr(status),
                                                      ptr(st["c_obs"]), ptr(st["uncer"]), ptr(st["mask8"]),
                                                      1 if st["c_obs"].ndim == 2 else 0, ptr(p1), ptr(p), ptr(st["chi"]),
-                                                     ptr(row), int(row_stride), pr.seed_int, st["counter"], 1 if first else 0))
+                                                     rowp, int(row_stride), pr.seed_int, counter, 1 if first else 0,
+                                                     self._chain0))
         return p
+
+    # ------------------------------------------------------------------ chain groups
+    GROUP_MIN_CHAINS = 4096         # fewer chains: one group (see chain_groups)
+
+    def chain_groups(self, C, groups=None):
+        """None, or a ``ChainGroups`` that advances the C chains as ``groups`` contiguous groups, each on its own stream.
+
+        Chains are independent, so nothing orders one group's lock step against another's: while one group's root search
+        drains (its last wavefronts leave SIMDs idle) and its small kernels run (proposal, stacks, prep, accept), the
+        other group's root search has the chip - 25 600 chains x 96 layers: 6.3 -> 5.4 ms per step of all chains with two
+        groups, 16 400 chains (one workgroup more than a full round of the root search): 5.1 -> 3.9 ms; never slower from
+        1 600 chains on (three groups: as two; four lose 10-25 %; profiles/r03b/chain_groups.txt).  A group's solve
+        carries SURFDISP_PIPELINED, so the library sizes its teams for both groups' stacks.  The random streams are
+        indexed by the chain's index in the whole sampler (``chain0``), so the chains - every mcTrack row - are the same
+        for any number of groups.  Default: two groups from ``GROUP_MIN_CHAINS`` chains on (``PYSURFINV_CHAIN_GROUPS``
+        overrides), one below."""
+        if groups is None:
+            env = os.environ.get("PYSURFINV_CHAIN_GROUPS")
+            groups = int(env) if env else (2 if C >= self.GROUP_MIN_CHAINS else 1)
+        groups = max(1, min(int(groups), C))
+        if groups == 1 or not self.fused_available():
+            return None
+        key = (C, groups)
+        if key not in self._groups:
+            self._groups[key] = ChainGroups(self, C, groups)
+        return self._groups[key]
 
     # ------------------------------------------------------------------ proposals
     def _good(self, p):
@@ -239,7 +329,7 @@ class MetropolisBatch:
         return new
 
     # ------------------------------------------------------------------ the sampler
-    def run(self, n_chains, chainL, init_first=True, priori=False, _init_mask=None, spec_depth=1, fused=None):
+    def run(self, n_chains, chainL, init_first=True, priori=False, _init_mask=None, spec_depth=1, fused=None, groups=None):
         """Advance ``n_chains`` chains for ``chainL`` steps each (= MCinvMP with runN = n_chains*chainL).
 
         Returns mcTrack float64 [n_chains, chainL, 3+N]; chain 0 starts at the initial model when
@@ -255,7 +345,8 @@ class MetropolisBatch:
         consumed differs (the exact-replay path of the reference trace uses d = 1).
 
         ``fused`` (default: whenever ``fused_available()``): the lock step as device kernels around the solver
-        (``fused_step``: Philox random numbers keyed by the proposer's seed; same proposal and accept distributions)."""
+        (``fused_step``: Philox random numbers keyed by the proposer's seed; same proposal and accept distributions).
+        ``groups``: chain groups of the fused path (``chain_groups``; the chains do not depend on it)."""
         if spec_depth > 1 and not priori:
             return self._run_speculative(n_chains, chainL, init_first, _init_mask, int(spec_depth))
         torch = self.torch
@@ -267,8 +358,18 @@ class MetropolisBatch:
             # propose / accept kernels around the solver: mcTrack rows are written by the accept kernel itself
             p = self._start(C, init_first, _init_mask).contiguous().clone()
             stride = chainL * (3 + N)
+            cg = self.chain_groups(C, groups)
+            base = self._counter
+            if cg is not None:
+                cg.fork()
             for i in range(chainL):
-                self.fused_step(p, row=track[0, i], row_stride=stride, first=(i == 0))
+                if cg is not None:
+                    cg.step(p, row=track, row_stride=stride, row_offset=i * (3 + N), first=(i == 0), counter=base + i + 1)
+                else:
+                    self.fused_step(p, row=track, row_stride=stride, row_offset=i * (3 + N), first=(i == 0), counter=base + i + 1)
+            if cg is not None:
+                cg.join()
+            self._counter = base + chainL
             return track
         p0 = self.reset(C) if not (init_first and C == 1) else None
         if init_first:
@@ -359,14 +460,14 @@ class MetropolisBatch:
                 i += 1
         return track
 
-    def run_points(self, n_points, chains_per_point, chainL, on_device=False):
+    def run_points(self, n_points, chains_per_point, chainL, on_device=False, groups=None):
         """MCinvMP for n_points at once: chain index = point * chains_per_point + k; chain k = 0 of
         every point starts at the initial model, the others at prior draws (point.py:95-99).
         Returns float64 [n_points, chains_per_point, chainL, 3+N] (numpy, or the device tensor)."""
         torch = self.torch
         C = n_points * chains_per_point
         first = (torch.arange(C, device=self.device) % chains_per_point) == 0
-        tr = self.run(C, chainL, init_first=False, _init_mask=first).reshape(n_points, chains_per_point, chainL, -1)
+        tr = self.run(C, chainL, init_first=False, _init_mask=first, groups=groups).reshape(n_points, chains_per_point, chainL, -1)
         return tr if on_device else tr.cpu().numpy()
 
     def summarise_points(self, track, obs_rows):

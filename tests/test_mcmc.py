@@ -276,16 +276,16 @@ def test_fused_device_kernels_proposal_and_accept():
     pr = mc.proposer
     v = torch.as_tensor(mb.spec.v0, device=dev)[None, :].repeat(C, 1).contiguous()
     new = torch.empty_like(v)
-    _lib.check(L.surfdisp_mcmc_propose_device(None, C, N, ptr(v), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step), 11, 1, 0, ptr(new)))
+    _lib.check(L.surfdisp_mcmc_propose_device(None, C, N, ptr(v), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step), 11, 1, 0, ptr(new), 0))
     torch.cuda.synchronize()
     assert bool(((new > pr.vmin) & (new < pr.vmax)).all())
     d = (new - v).cpu().numpy()
     assert abs(d[:, 4].std() / mb.spec.step[4] - 1) < 0.03 and abs(d[:, 4].mean()) < 3 * mb.spec.step[4] / 100
     new2 = torch.empty_like(v)
-    _lib.check(L.surfdisp_mcmc_propose_device(None, C, N, ptr(v), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step), 11, 2, 0, ptr(new2)))
+    _lib.check(L.surfdisp_mcmc_propose_device(None, C, N, ptr(v), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step), 11, 2, 0, ptr(new2), 0))
     assert float((new2 - new).abs().max()) > 0                       # another counter, another draw
     rs = torch.empty_like(v)
-    _lib.check(L.surfdisp_mcmc_propose_device(None, C, N, ptr(v), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step), 11, 3, 1, ptr(rs)))
+    _lib.check(L.surfdisp_mcmc_propose_device(None, C, N, ptr(v), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step), 11, 3, 1, ptr(rs), 0))
     torch.cuda.synchronize()
     assert bool(((rs >= pr.vmin) & (rs <= pr.vmax)).all()) and abs(rs[:, 3].mean().item() - 35.0) < 0.3
     # accept kernel: two lock steps through the sampler's own entry, rows compared with the torch misfit
@@ -330,3 +330,36 @@ def test_fused_run_records_consistent_rows():
     tr2 = mc2.run(256, 40, fused=False)
     a1, a2 = float(tr[:, 1:, 2].mean()), float(tr2[:, 1:, 2].mean())
     assert abs(a1 - a2) < 0.05, (a1, a2)
+
+
+@pytest.mark.gpu
+def test_chain_groups_do_not_change_the_chains():
+    """MetropolisBatch.chain_groups: the chains advance as groups on their own streams; the random streams are indexed by
+    the chain's index in the whole sampler (chain0 of the C ABI), so every mcTrack row is the same for 1, 2 and 3 groups -
+    with per-chain observations and per-point local information threaded through the groups."""
+    dev = torch.device("cuda:0")
+    mb = Model1DBatch(CONT, device=dev)
+    C, chainL, P = 600, 12, len(G["trace/periods"])
+    rng = np.random.default_rng(5)
+    c_obs = np.tile(G["trace/c_obs"], (C, 1)) * (1 + 0.01 * rng.standard_normal((C, 1)))
+    c_obs[::5, 2] = np.nan
+    unc = np.tile(G["trace/uncer"], (C, 1))
+    tracks = []
+    for groups in (1, 2, 3):
+        mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], c_obs, unc, device=dev, seed=21)
+        first = (torch.arange(C, device=dev) % 50) == 0
+        tr = mc.run(C, chainL, init_first=False, _init_mask=first, groups=groups)
+        torch.cuda.synchronize()
+        assert mc.n_forward == C * chainL and mc._counter == chainL
+        assert (mc.chain_groups(C, groups) is None) == (groups == 1)
+        tracks.append(tr.cpu().numpy())
+        # a second run continues the counter: other random numbers
+        tr2 = mc.run(C, chainL, init_first=False, _init_mask=first, groups=groups)
+        assert mc._counter == 2 * chainL and not np.array_equal(tr2.cpu().numpy()[:, 1:], tracks[-1][:, 1:])
+    assert np.array_equal(tracks[0], tracks[1]) and np.array_equal(tracks[0], tracks[2])
+    acc = tracks[0][:, 1:, 2].mean()
+    assert 0.05 < acc < 0.95
+    # default rule: one group below GROUP_MIN_CHAINS, two from there on
+    mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], G["trace/c_obs"], G["trace/uncer"], device=dev, seed=1)
+    assert mc.chain_groups(MetropolisBatch.GROUP_MIN_CHAINS - 1) is None
+    assert mc.chain_groups(MetropolisBatch.GROUP_MIN_CHAINS).G == 2
