@@ -198,11 +198,13 @@ class Runtime:
         return self.max_over_ranks(time.perf_counter() - t0)[0]
 
 
-def leg_roofline(leg, live_ms, alg_bytes_per_launch, kernel_prefix="surfdisp_phase_kernel<2,", team=None):
+def leg_roofline(leg, live_ms, alg_bytes_per_launch, kernel_prefix="surfdisp_phase_kernel<2,", team=None, chip=None):
     """Roofline block of a side leg: its dominant kernel (the Rayleigh root search), VALU-bound.  achieved = wave-level
     VALU instructions per launch (rocprofv3 --pmc pass of THIS library build on this leg, profiles/traffic_<leg>.json,
     written by scripts/profile_leg.sh + scripts/summarise_leg.py) / the LIVE average duration of that kernel (HIP events
-    on its stream inside this run); the HBM figure north_star asks for is beside it."""
+    on its stream inside this run); the HBM figure north_star asks for is beside it.  ``chip`` = (launches of this kernel
+    per step, step duration in ms) when several launches share the chip (chain groups): the chip-level share beside the
+    per-launch one, whose live duration includes the time the launch shares SIMDs with its neighbour."""
     live_s = live_ms * 1e-3
     hbm = alg_bytes_per_launch / live_s / 1e9 if live_s > 0 else None
     roof = {"bound": "valu", "kernel": None, "unit": "wave-level VALU instructions/s", "peak": VALU_PEAK,
@@ -233,6 +235,14 @@ def leg_roofline(leg, live_ms, alg_bytes_per_launch, kernel_prefix="surfdisp_pha
                      "lane_utilisation": v.get("lane_utilisation"), "mean_waves_per_simd": v.get("mean_waves_per_simd"),
                      "pmc_profile": tj.get("round"), "pmc_lib_sha256_16": tj.get("lib_sha256_16"), "this_lib_sha256_16": here,
                      "pmc_matches_this_build": tj.get("lib_sha256_16") == here})
+        if chip is not None and chip[1] > 0:
+            n, step_s = int(chip[0]), chip[1] * 1e-3
+            issue = (v["valu_issue_frac_measured_costs"] * (v["kernel_cycles"] / CLOCK_HZ) if "valu_issue_frac_measured_costs" in v else None)
+            roof["chip_level"] = {"launches_per_step": n, "step_ms": chip[1],
+                                  "frac": n * v["valu_wave_instructions"] / step_s / VALU_PEAK,
+                                  "frac_measured_issue_costs": n * issue / step_s if issue is not None else None,
+                                  "note": "all launches of this kernel in one step / the step's duration (the small kernels "
+                                          "of the step included in the time, not in the instructions)"}
     except Exception as e:
         roof["note"] = f"profiles/traffic_{leg}.json unreadable: {e}"
     return roof
@@ -434,7 +444,8 @@ def workload_grid(rt, args, steps=None, warmup=None):
                           "how": "HIP events on the launch stream around the solver's kernels of the K timed lock steps"
                                  + (f" (first of {cg.G} chain groups, {Cl} chains per launch; the groups' streams share the chip, so a "
                                     "kernel's duration includes the time it shares SIMDs with the other group's kernels)" if cg is not None else "")},
-            "roofline": leg_roofline("grid", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * Cl, team=team),
+            "roofline": leg_roofline("grid", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * Cl, team=team,
+                                     chip=(cg.G, elapsed / K * 1e3) if cg is not None else None),
             "value": rt.world * C * K / elapsed, "forward_solves_per_s": rt.world * C * K / elapsed,
             "ms_per_step": elapsed / K * 1e3, "steps": K, "warmup": W, "n_gpus": rt.world, "scaling": "weak",
             "config": {"workload": "BASELINE configs[3] share per GPU: 512 points x 50 chains, 96-layer continental model, "
