@@ -90,6 +90,31 @@ def test_per_point_stacks_on_gpu(name):
         assert float(((model - mt).abs() / mt.abs().clamp(min=1e-3)).max()) < 2e-6
 
 
+@pytest.mark.gpu
+def test_grid_with_local_info_is_the_same_for_any_chain_grouping():
+    """run_grid on the device path with per-point constants: the chains advance as one launch per step or as chain groups on
+    their own streams (each group reads its own rows of the local-information table and of the observations) - same mcTrack."""
+    from pysurfinv_amd import grid
+    keys, table = LOCAL_TABLES["hyb"]
+    table = np.asarray(table, float)
+    npts, chains, chainL = table.shape[0], 7, 5
+    periods = np.asarray([8.0, 12.0, 18.0, 25.0, 33.0, 45.0, 60.0], np.float32)
+    rng = np.random.default_rng(2)
+    c_obs = 3.6 + 0.4 * np.linspace(0, 1, len(periods))[None, :] + 0.02 * rng.standard_normal((npts, len(periods)))
+    unc = np.full_like(c_obs, 0.03)
+    out = []
+    for g in (1, 2, 3):
+        m = Model1DBatch(SETTINGS["hyb"], device="cuda:0", local_keys=keys)
+        r = grid.run_grid(m, np.arange(npts), np.zeros(npts), periods, c_obs, unc, chains, chainL, device="cuda:0", seed=5,
+                          local_info=table, chain_groups=g)
+        out.append((r["mcTrack"], r["summaries"]))
+    assert out[0][0].shape == (npts, chains * chainL, 3 + m.spec.n)
+    for tr, sm in out[1:]:
+        assert np.array_equal(tr, out[0][0]) and np.allclose(sm, out[0][1], rtol=0, atol=1e-12, equal_nan=True)
+    # the points' constants really reach the chains: two points' first rows (the initial model) have different misfits
+    assert len(np.unique(np.round(out[0][0][:, 0, 0], 9))) > npts // 2
+
+
 # ------------------------------------------------------------------ sharded grid with heterogeneous points (gloo, CPU)
 NPTS, CHAINS, CHAINL = 6, 2, 3
 
