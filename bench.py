@@ -388,7 +388,7 @@ def workload_grid(rt, args, steps=None, warmup=None):
     track_row = torch.zeros((C, 3 + mb.spec.n), dtype=torch.float64, device=rt.dev)
 
     # chain groups as the library forms them (MetropolisBatch.chain_groups: two from 4 096 chains on, each on its own
-    # stream; BENCH_GRID_GROUPS overrides) - the chains themselves do not depend on the grouping
+    # stream; BENCH_GRID_GROUPS overrides) - every chain draws the same random numbers however they are grouped
     genv = os.environ.get("BENCH_GRID_GROUPS")
     cg = mc.chain_groups(C, int(genv) if genv else None) if fused else None
 

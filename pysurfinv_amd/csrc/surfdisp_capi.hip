@@ -29,6 +29,9 @@ struct EnvKnobs {
     int device = 0;               // SURFDISP_DEVICE (fast_surf_)
     int balance = -1;             // SURFDISP_BALANCE (developer knob): wavefront priority by progress, -1 = automatic
     int lockstep = -1;            // SURFDISP_LOCKSTEP (developer knob): -1 = automatic (on), 0 / 1, 2 = also for (stack, period) units
+    int host_slots = 3;           // SURFDISP_HOST_SLOTS (developer knob): chunks in flight of a large host-buffer call (2 or 3)
+    long host_chunk_layers = 327680;   // SURFDISP_HOST_CHUNK (developer knob): layers' worth of stacks per chunk
+    int host_pipeline = 1;        // SURFDISP_HOST_PIPELINE (developer knob): 0 = large host-buffer calls as one chunk
     int rows_min_team = 8;        // SURFDISP_ROWS_MIN_TEAM (developer knob): teams of at least this many lanes rebuild from the row copy
 #ifdef SD_ELL_INKERNEL_WIDE
     int ell_kernel = 0;           // A/B build: the ellipticity recursions inside the root search for every team size (r02)
@@ -49,6 +52,9 @@ struct EnvKnobs {
         if (const char *e = getenv("SURFDISP_BALANCE")) balance = atoi(e);
         if (const char *e = getenv("SURFDISP_ROWS_MIN_TEAM")) rows_min_team = atoi(e);
         if (const char *e = getenv("SURFDISP_LOCKSTEP")) lockstep = atoi(e);
+        if (const char *e = getenv("SURFDISP_HOST_PIPELINE")) host_pipeline = atoi(e);
+        if (const char *e = getenv("SURFDISP_HOST_SLOTS")) host_slots = atoi(e);
+        if (const char *e = getenv("SURFDISP_HOST_CHUNK")) { host_chunk_layers = atol(e); if (host_chunk_layers < 1024) host_chunk_layers = 1024; }
     }
 };
 const EnvKnobs &knobs() { static const EnvKnobs k; return k; }
@@ -556,6 +562,105 @@ struct HostArena {
 thread_local HostArena g_arena;
 }  // namespace
 
+// Large host-buffer calls: a grow-only device buffer and three streams per calling thread (no hipMalloc / hipFree per
+// call), the batch cut into chunks that take turns on the streams - chunk k+1's copy-in and chunk k-1's copy-out run
+// beside chunk k's kernels, and consecutive chunks' kernels overlap as independent batches in flight do.  Measured
+// (scripts/time_host_api.py, C call, host buffers in and out): 65 536 x L10 3.07 -> 2.26 ms (21 -> 29 M solves/s),
+// 262 144 x L10 11.4 -> 7.7 ms (23 -> 34 M); slots 2 / 3 and chunks of 16 384 / 32 768 / 65 536 ten-layer stacks swept.
+struct HostPipe {
+    int dev = -1;
+    char *d = nullptr;
+    size_t cap = 0;
+    hipStream_t s[3] = {nullptr, nullptr, nullptr};
+    bool ensure(int device, size_t bytes)
+    {
+        if (dev != device) { release(); dev = device; }
+        for (int i = 0; i < 3; ++i)
+            if (!s[i] && hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) return false;
+        if (bytes > cap) {
+            if (d) (void)hipFree(d);
+            d = nullptr; cap = 0;
+            if (hipMalloc(reinterpret_cast<void **>(&d), bytes) != hipSuccess) return false;
+            cap = bytes;
+        }
+        return true;
+    }
+    void release()
+    {
+        if (d) (void)hipFree(d);
+        for (int i = 0; i < 3; ++i) { if (s[i]) (void)hipStreamDestroy(s[i]); s[i] = nullptr; }
+        d = nullptr; cap = 0;
+    }
+    // no destructor on purpose (see HostArena)
+};
+thread_local HostPipe g_pipe;
+constexpr size_t PIPE_KEEP_MAX = (size_t)3 << 30;      // a larger buffer is given back after the call
+
+// chunks of a large host-buffer call: about 327 680 layers' worth of stacks each (32 768 ten-layer stacks), at least two;
+// stacks of more than 20 layers go through in one piece (16 384 x L64: 3.56 ms either way, 25 600 x L96: 8.65 against 9.35 ms)
+static int host_chunks(int B, int Lmax)
+{
+    long bc = (long)knobs().host_chunk_layers / Lmax;
+    if (bc < 16384) return 1;          // deep stacks: the copies are a tenth of the call and smaller launches cost more than they hide
+    if (bc > 65536) bc = 65536;
+    if (B < bc) return 1;
+    const long n = (B + bc - 1) / bc;
+    return (int)(n < 2 ? 2 : n);
+}
+
+static int forward_batch_pipelined(int device, int nch, int B, int Lmax, const int *nlay, const float *model,
+                                   int P, const float *per, int kind, float *c, float *u, int *status)
+{
+    const int Bc = (int)((((long)B + nch - 1) / nch + 63) / 64 * 64);          // stacks per chunk (the last one may be shorter)
+    const size_t nm = (size_t)Bc * 5 * Lmax * sizeof(float), np = (size_t)P * sizeof(float);
+    const size_t ni = (size_t)Bc * sizeof(int), no = (size_t)Bc * P * sizeof(float);
+    const size_t ws = surfdisp_workspace_bytes(Bc, Lmax, P);
+    const size_t o_model = 0, o_per = o_model + align_up(nm), o_nl = o_per + align_up(np), o_c = o_nl + align_up(ni);
+    const size_t o_u = o_c + align_up(no), o_st = o_u + align_up(no), o_ws = o_st + align_up(ni), slot = align_up(o_ws + ws);
+    const int NS = knobs().host_slots >= 3 ? 3 : 2;
+    if (!g_pipe.ensure(device, NS * slot)) { set_err("host-buffer pipeline: allocation failed"); return SURFDISP_ERR_HIP; }
+    int ret = SURFDISP_SUCCESS;
+    auto copy_out = [&](int k) -> bool {                   // chunk k's results to the caller's arrays (stream-ordered behind its kernels)
+        char *d = g_pipe.d + (size_t)(k % NS) * slot;
+        hipStream_t s = g_pipe.s[k % NS];
+        const long b0 = (long)k * Bc;
+        const size_t bc = (size_t)((B - b0) < Bc ? (B - b0) : Bc);
+        return hipMemcpyAsync(c + b0 * P, d + o_c, bc * P * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess &&
+               (!u || hipMemcpyAsync(u + b0 * P, d + o_u, bc * P * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess) &&
+               (!status || hipMemcpyAsync(status + b0, d + o_st, bc * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess);
+    };
+    int k = 0;
+    for (; k < nch && ret == SURFDISP_SUCCESS; ++k) {
+        char *d = g_pipe.d + (size_t)(k % NS) * slot;
+        hipStream_t s = g_pipe.s[k % NS];
+        const long b0 = (long)k * Bc;
+        const int bc = (int)((B - b0) < Bc ? (B - b0) : Bc);
+        if (bc <= 0) break;
+        // the slot's previous chunk leaves first (a copy to pageable memory holds the calling thread until that chunk is
+        // done - the other slot's chunk is computing meanwhile)
+        if (k >= NS && !copy_out(k - NS)) { set_err("device->host copy failed"); ret = SURFDISP_ERR_HIP; break; }
+        const bool ok = hipMemcpyAsync(d + o_model, model + (size_t)b0 * 5 * Lmax, (size_t)bc * 5 * Lmax * sizeof(float), hipMemcpyHostToDevice, s) == hipSuccess &&
+                        (k >= NS || hipMemcpyAsync(d + o_per, per, np, hipMemcpyHostToDevice, s) == hipSuccess) &&
+                        (!nlay || hipMemcpyAsync(d + o_nl, nlay + b0, (size_t)bc * sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess);
+        if (!ok) { set_err("host->device copy failed"); ret = SURFDISP_ERR_HIP; break; }
+        ret = surfdisp_forward_batch_device(s, bc, Lmax, nlay ? reinterpret_cast<int *>(d + o_nl) : nullptr,
+                                            reinterpret_cast<float *>(d + o_model), P, reinterpret_cast<float *>(d + o_per),
+                                            kind | SURFDISP_PIPELINED, reinterpret_cast<float *>(d + o_c),
+                                            u ? reinterpret_cast<float *>(d + o_u) : nullptr,
+                                            reinterpret_cast<int *>(d + o_st), d + o_ws, ws);
+    }
+    if (ret == SURFDISP_SUCCESS) {
+        for (int j = (k >= NS ? k - NS : 0); j < k; ++j)
+            if (!copy_out(j)) { set_err("device->host copy failed"); ret = SURFDISP_ERR_HIP; break; }
+    }
+    for (int i = 0; i < NS; ++i) {
+        hipError_t e = hipStreamSynchronize(g_pipe.s[i]);
+        if (e != hipSuccess && ret == SURFDISP_SUCCESS) { set_err("kernel execution failed: %s", hipGetErrorString(e)); ret = SURFDISP_ERR_HIP; }
+    }
+    if (g_pipe.cap > PIPE_KEEP_MAX) g_pipe.release();
+    return ret;
+}
+
 int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const float *model,
                            int P, const float *per, int kind,
                            float *c, float *u, int *status)
@@ -590,14 +695,19 @@ int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const f
     const size_t o_st = o_u + align_up(no);
     const size_t o_ws = o_st + align_up(ni);
     const bool small = (o_ws + ws) <= ARENA_MAX;
+    if (!small) {
+        const int nch = knobs().host_pipeline ? host_chunks(B, Lmax) : 1;
+        if (nch > 1) return forward_batch_pipelined(device, nch, B, Lmax, nlay, model, P, per, kind, c, u, status);
+    }
     char *d = nullptr, *h = nullptr;
+    hipStream_t s = nullptr;
     if (small) {
         if (!g_arena.reserve(device, o_ws + ws, o_ws)) { set_err("arena allocation failed"); return SURFDISP_ERR_HIP; }
         d = g_arena.d; h = g_arena.h;
     } else {
-        SD_HIP(hipMalloc(reinterpret_cast<void **>(&d), o_ws + ws));
+        if (!g_pipe.ensure(device, o_ws + ws)) { set_err("host-buffer call: allocation failed"); return SURFDISP_ERR_HIP; }
+        d = g_pipe.d; s = g_pipe.s[0];
     }
-    hipStream_t s = nullptr;
     int ret = SURFDISP_SUCCESS;
     do {
         bool ok;
@@ -623,7 +733,7 @@ int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const f
             ok = hipMemcpyAsync(h + o_c, d + o_c, o_ws - o_c, hipMemcpyDeviceToHost, s) == hipSuccess;
         } else {
             ok = hipMemcpyAsync(c, d + o_c, no, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                 hipMemcpyAsync(u, d + o_u, no, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 (!u || hipMemcpyAsync(u, d + o_u, no, hipMemcpyDeviceToHost, s) == hipSuccess) &&
                  (!status || hipMemcpyAsync(status, d + o_st, ni, hipMemcpyDeviceToHost, s) == hipSuccess);
         }
         if (!ok) { set_err("device->host copy failed"); ret = SURFDISP_ERR_HIP; break; }
@@ -631,11 +741,11 @@ int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const f
         if (e != hipSuccess) { set_err("kernel execution failed: %s", hipGetErrorString(e)); ret = SURFDISP_ERR_HIP; break; }
         if (small) {
             memcpy(c, h + o_c, no);
-            memcpy(u, h + o_u, no);
+            if (u) memcpy(u, h + o_u, no);
             if (status) memcpy(status, h + o_st, ni);
         }
     } while (0);
-    if (!small) (void)hipFree(d);
+    if (!small && g_pipe.cap > PIPE_KEEP_MAX) g_pipe.release();
     return ret;
 }
 

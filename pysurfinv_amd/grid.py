@@ -42,7 +42,7 @@ def run_grid(model_batch, lons, lats, periods, c_obs, uncer, chains_per_point, c
                   (``Model1DBatch.set_local_info``); every chain reads its point's row.
     c_obs, uncer: [n_points, P] (NaN / non-positive uncertainty = masked period)
     chain_groups: None (the sampler's default: two groups of chains on two streams from 4 096 chains per rank on,
-                  ``MetropolisBatch.chain_groups``) or their number; the chains do not depend on it
+                  ``MetropolisBatch.chain_groups``) or their number; the random numbers of every chain do not depend on it
     Returns dict(points=(lo, hi), mcTrack=[n_local, chains*chainL, 3+N] or None, summaries=[n_points, 6+2N+P]
     (every rank holds all rows, point order), columns, elapsed (sampling + summaries + gather, this rank),
     elapsed_write, report).  ``report`` carries the MAX over ranks of ``elapsed`` and the summed counters."""

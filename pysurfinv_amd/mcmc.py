@@ -275,8 +275,10 @@ class MetropolisBatch:
         groups, 16 400 chains (one workgroup more than a full round of the root search): 5.1 -> 3.9 ms; never slower from
         1 600 chains on (three groups: as two; four lose 10-25 %; profiles/r03b/chain_groups.txt).  A group's solve
         carries SURFDISP_PIPELINED, so the library sizes its teams for both groups' stacks.  The random streams are
-        indexed by the chain's index in the whole sampler (``chain0``), so the chains - every mcTrack row - are the same
-        for any number of groups.  Default: two groups from ``GROUP_MIN_CHAINS`` chains on (``PYSURFINV_CHAIN_GROUPS``
+        indexed by the chain's index in the whole sampler (``chain0``), so every chain draws the same numbers for any number
+        of groups: the chains - every mcTrack row - are then identical whenever the groups' launches use the lanes per stack
+        the whole batch would (deep stacks: always 16 from 2 048 per launch on; tests/test_mcmc.py), and otherwise differ by
+        what the solver's answers differ between team sizes (1e-6, which can flip a borderline accept).  Default: two groups from ``GROUP_MIN_CHAINS`` chains on (``PYSURFINV_CHAIN_GROUPS``
         overrides), one below."""
         if groups is None:
             env = os.environ.get("PYSURFINV_CHAIN_GROUPS")
@@ -346,7 +348,7 @@ class MetropolisBatch:
 
         ``fused`` (default: whenever ``fused_available()``): the lock step as device kernels around the solver
         (``fused_step``: Philox random numbers keyed by the proposer's seed; same proposal and accept distributions).
-        ``groups``: chain groups of the fused path (``chain_groups``; the chains do not depend on it)."""
+        ``groups``: chain groups of the fused path (``chain_groups``; every chain's random numbers do not depend on it)."""
         if spec_depth > 1 and not priori:
             return self._run_speculative(n_chains, chainL, init_first, _init_mask, int(spec_depth))
         torch = self.torch

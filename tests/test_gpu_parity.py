@@ -237,6 +237,39 @@ def test_full_size_properties_config2(hip):
     assert relerr(c[idx], co) < TOL_C and relerr(u[idx], uo) < TOL_U
 
 
+@pytest.mark.parametrize("B,L,kind", [(70000, 10, 2), (70000, 10, 1), (40000, 20, 2), (20000, 64, 2), (150001, 6, 2)])
+def test_large_host_buffer_calls_are_chunked_and_pipelined(hip, B, L, kind):
+    """surfdisp_forward_batch on large host buffers: the batch goes through the device in chunks alternating between two
+    streams (copies beside kernels, chunks in flight beside each other; uneven last chunk, ragged layer counts) - same
+    answers as the one-launch device entry; a phase-only call may pass u = NULL."""
+    import torch
+    from pysurfinv_amd import _lib, synth, forward
+    per = synth.default_periods(17)
+    model = synth.synth_models(B, L, seed=9, **({} if L == 10 else {"total_thickness": 220.0}))
+    nlay = np.full(B, L, np.int32)
+    nlay[::11] = max(2, L - 3)
+    # (stacks of more than 20 layers go through in one piece, on the calling thread's cached buffer and stream)
+    c, u, st = forward.forward_batch(model, per, kind=kind, nlay=nlay)
+    plan = forward.BatchPlan(B, L, len(per))
+    cd, ud, sd = plan.run(torch.from_numpy(model).cuda(), torch.from_numpy(per).cuda(), kind=kind, nlay=torch.from_numpy(nlay).cuda())
+    torch.cuda.synchronize()
+    # same zero pattern and status; values to the spread between team sizes (a chunk's launch may use other teams than
+    # the whole batch's: the refinement subdivides its bracket G ways; 99.9 % of the roots agree to 2e-6, all to 3e-5)
+    cd, ud = cd.cpu().numpy(), ud.cpu().numpy()
+    assert np.array_equal(st, sd.cpu().numpy()) and np.array_equal(c > 0, cd > 0)
+    q = lambda a, b: float(np.quantile(np.abs(a[b > 0].astype(np.float64) / b[b > 0] - 1), 0.999))
+    assert relerr(c, cd) < 3e-5 and q(c, cd) < 2e-6, (relerr(c, cd), q(c, cd))
+    assert relerr(u, ud) < 2e-3 and q(u, ud) < 2e-5, (relerr(u, ud), q(u, ud))
+    assert (c > 0).mean() > 0.99
+    # phase only, no group-velocity and no status array
+    lib = _lib.lib()
+    c2 = np.full((B, len(per)), -1.0, np.float32)
+    fp = lambda x: x.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    _lib.check(lib.surfdisp_forward_batch(0, B, L, nlay.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), fp(model), len(per), fp(per),
+                                          kind | _lib.PHASE_ONLY, fp(c2), None, None))
+    assert np.array_equal(c2, c)
+
+
 def test_extreme_velocities_follow_the_reference(hip):
     """Stacks far outside seismology.  Vs x 3 (roots up to ~14 km/s) must agree with the oracle.  Vs x 6 puts the
     roots above 16 km/s, where one fp32 ulp (1.9e-6) exceeds NEVILL's 1e-6 bracket tolerance: the REFERENCE never
