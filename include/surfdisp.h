@@ -109,10 +109,16 @@ void fast_surf_(const int *n_layer, const int *kind,
  *   nlay   [B] or NULL (every stack has Lmax layers); unused tail entries of a row are ignored
  *   per    [P] ascending periods (s);   kind = 1 Love | 2 Rayleigh
  *   c, u   [B][P] phase / group velocity (km/s), 0 where unsolved;  status [B] or NULL
- * Copies in, runs the kernels on `device`, copies out.  Returns SURFDISP_SUCCESS or an error. */
+ * Copies in, runs the kernels on `device`, copies out.  Returns SURFDISP_SUCCESS or an error.
+ * The calling THREAD keeps what the call needed on the device for its next call (fast_surf_ too): a small arena + pinned
+ * staging buffer for small calls, a grow-only buffer (given back at once beyond 3 GiB) and three streams for large ones,
+ * which - stacks of up to 20 layers - go through the device in chunks of ~32 768 stacks taking turns on those streams
+ * (copies beside kernels).  surfdisp_thread_release() frees the calling thread's share (a thread that is about to exit
+ * calls it; a thread pool need not). */
 int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const float *model,
                            int P, const float *per, int kind,
                            float *c, float *u, int *status);
+void surfdisp_thread_release(void);
 
 /* ---- (3) batched solve, DEVICE pointers, stream-ordered, no allocation, no host sync:
  *          safe to capture in a hipGraph.  `stream` is a hipStream_t (NULL = default stream).

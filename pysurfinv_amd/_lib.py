@@ -25,7 +25,7 @@ NPER_MAX, NLAY_MAX = 200, 200
 
 # every symbol include/surfdisp.h declares
 EXPORTS = (
-    "fast_surf_", "surfdisp_forward_batch", "surfdisp_workspace_bytes",
+    "fast_surf_", "surfdisp_forward_batch", "surfdisp_thread_release", "surfdisp_workspace_bytes",
     "surfdisp_forward_batch_device", "surfdisp_forward_batch_device2", "surfdisp_forward_batch_device_timed",
     "surfdisp_forward_batch_device_events", "surfdisp_events_create", "surfdisp_events_destroy",
     "surfdisp_events_elapsed_ms", "surfdisp_stream_wait_event", "surfdisp_params_to_model_device",
@@ -114,6 +114,8 @@ def lib() -> ctypes.CDLL:
     L.surfdisp_mcmc_accept_device.restype = ctypes.c_int
     L.surfdisp_mcmc_accept_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int,
                                               vp, vp, vp, vp, ctypes.c_long, u64, u64, ctypes.c_int, ctypes.c_long]
+    L.surfdisp_thread_release.restype = None
+    L.surfdisp_thread_release.argtypes = []
     L.surfdisp_workspace_fallback_count.restype = ctypes.c_int
     L.surfdisp_workspace_fallback_count.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip]
     L.surfdisp_set_team.restype = ctypes.c_int

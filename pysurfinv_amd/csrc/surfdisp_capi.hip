@@ -749,6 +749,15 @@ int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const f
     return ret;
 }
 
+// frees what the host-buffer entries cached for the calling thread (device arena, pinned staging, pipeline buffer, streams)
+void surfdisp_thread_release(void)
+{
+    g_arena.release();
+    g_arena.dev = -1;
+    g_pipe.release();
+    g_pipe.dev = -1;
+}
+
 // Fortran-ABI drop-in for the reference object's symbol (fast_surf.f:2-5).
 void fast_surf_(const int *n_layer, const int *kind,
                 const float *vp, const float *vs, const float *rho,

@@ -261,6 +261,12 @@ def test_large_host_buffer_calls_are_chunked_and_pipelined(hip, B, L, kind):
     assert relerr(c, cd) < 3e-5 and q(c, cd) < 2e-6, (relerr(c, cd), q(c, cd))
     assert relerr(u, ud) < 2e-3 and q(u, ud) < 2e-5, (relerr(u, ud), q(u, ud))
     assert (c > 0).mean() > 0.99
+    # the calling thread's cached buffers and streams can be given back; the next call builds them again
+    lib0 = _lib.lib()
+    lib0.surfdisp_thread_release()
+    c3, u3, st3 = forward.forward_batch(model[:4096], per, kind=kind, nlay=nlay[:4096])
+    assert np.array_equal(st3, st[:4096]) and relerr(c3, cd[:4096]) < 3e-5
+    lib0.surfdisp_thread_release()
     # phase only, no group-velocity and no status array
     lib = _lib.lib()
     c2 = np.full((B, len(per)), -1.0, np.float32)
