@@ -460,7 +460,8 @@ def workload_grid(rt, args, steps=None, warmup=None):
 
 def workload_mcmc(rt, args, steps=None, warmup=None):
     """BASELINE configs[2]: one surface point, 100 000 Metropolis steps as 100 chains x 1000 (the reference's
-    MCinvMP layout, point.py:90-125), here the rate of the lock step (100 chains), plain and replayed from a HIP graph."""
+    MCinvMP layout, point.py:90-125), here the rate of the 100 chains' steps: the library's default (speculative lock
+    steps), one step per solve, the (stack, period) decomposition, and the torch-glue step replayed from a HIP graph."""
     from pysurfinv_amd.mcmc import MetropolisBatch
     K = steps if steps is not None else max(args.steps, 50)
     mb, c_obs, unc = _mcmc_setup(rt, 1, 100)
@@ -469,17 +470,28 @@ def workload_mcmc(rt, args, steps=None, warmup=None):
                                   "96-layer continental model, 19 periods, Rayleigh phase-only misfit", "chains": 100}}
     mc = MetropolisBatch(mb.spec, mb.to_model, MCMC_PERIODS, c_obs[0], unc[0], device=rt.dev, seed=3 + rt.rank)
     from pysurfinv_amd import _lib, forward
-    mc.run(100, 4); rt.barrier()
-    mc.event_ring = forward.EventRing(K)
-    t0 = time.perf_counter(); mc.run(100, K + 1); rt.barrier()
+    # the sampler as the library runs it for 100 chains: speculative lock steps (MetropolisBatch.auto_spec_depth = 3: the
+    # tree of the next three accept / reject outcomes, 7 proposals per chain, ONE batched solve of 700 stacks, three
+    # Metropolis steps; the chain is distributed as the plain sampler's) - and, beside it, one step per solve
+    d = mc.auto_spec_depth(100)
+    M = (1 << d) - 1
+    K3 = -(-K // d) * d                                    # timed steps: whole lock steps
+    mc.run(100, 1 + 2 * d); rt.barrier()
+    mc.event_ring = forward.EventRing(K3 // d + 1)
+    t0 = time.perf_counter(); mc.run(100, K3 + 1); rt.barrier()
     dt, = rt.max_over_ranks(time.perf_counter() - t0)
-    kms = mc.event_ring.kernel_ms().mean(axis=0)
+    kms = mc.event_ring.kernel_ms()[1:].mean(axis=0)        # (slot 0: the start models' own solve)
     mc.event_ring = None
     L = int(mb.to_model(mc.reset(2))[0].shape[2])
-    out.update({"value": rt.world * 100 * K / dt, "ms_per_lock_step": dt / K * 1e3, "steps": K, "scaling": "weak",
+    out.update({"value": rt.world * 100 * K3 / dt, "ms_per_step": dt / K3 * 1e3, "ms_per_lock_step": dt / (K3 // d) * 1e3,
+                "spec_depth": d, "stacks_per_lock_step": 100 * M, "steps": K3, "scaling": "weak",
                 "kernel_ms": {"prep": kms[0], "phase": kms[1], "finish": kms[2]},
-                "roofline": leg_roofline("mcmc", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * 100,
-                                         team=int(_lib.lib().surfdisp_get_team2(100, L, len(MCMC_PERIODS), _lib.KIND_RAYLEIGH | _lib.PHASE_ONLY)))})
+                "roofline": leg_roofline("mcmc", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * 100 * M,
+                                         team=int(_lib.lib().surfdisp_get_team2(100 * M, L, len(MCMC_PERIODS), _lib.KIND_RAYLEIGH | _lib.PHASE_ONLY)))})
+    mc.run(100, 4, spec_depth=1); rt.barrier()
+    t0 = time.perf_counter(); mc.run(100, K + 1, spec_depth=1); rt.barrier()
+    dt1, = rt.max_over_ranks(time.perf_counter() - t0)
+    out.update({"value_one_step_per_solve": rt.world * 100 * K / dt1, "ms_per_lock_step_one_step_per_solve": dt1 / K * 1e3})
     # the same lock step with the opt-in (stack, period) decomposition for small chain counts (independent="auto")
     mca = MetropolisBatch(mb.spec, mb.to_model, MCMC_PERIODS, c_obs[0], unc[0], device=rt.dev, seed=3 + rt.rank, independent="auto")
     mca.run(100, 4); rt.barrier()

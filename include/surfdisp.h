@@ -221,6 +221,21 @@ int surfdisp_mcmc_accept_device(void *stream, int C, int N, int P, const float *
                                 const double *c_obs, const double *uncer, const unsigned char *mask, int obs_per_chain,
                                 const double *p1, double *p0, double *chi0, double *row, long row_stride,
                                 unsigned long long seed, unsigned long long counter, int first, long chain0);
+/* The SPECULATIVE lock step for few chains (a lock step of 100 chains leaves the chip idle, so it costs no more to solve
+ * several proposals per chain): propose_tree draws the binary tree of the next `depth` (1..4) accept / reject outcomes -
+ * node k's proposal from the state its branch would be in (node 0: the chain's state; child 2k+1 "accepted": proposal k;
+ * child 2k+2 "rejected": the state of k), out [C][2^depth - 1][N] = the C * (2^depth - 1) stacks of ONE batched solve;
+ * accept_tree then walks nsteps <= depth steps per chain with the usual test at every node and writes one mcTrack row
+ * per step, step_stride doubles apart.  Every proposal is drawn from, and tested against, the state the chain is in at
+ * that step, so the chain is distributed exactly as the plain sampler's.  depth = 1 is the plain pair of calls above. */
+int surfdisp_mcmc_propose_tree_device(void *stream, int C, int N, int depth, const double *p, const double *vmin,
+                                      const double *vmax, const double *step, unsigned long long seed,
+                                      unsigned long long counter, double *out, long chain0);
+int surfdisp_mcmc_accept_tree_device(void *stream, int C, int N, int P, int depth, int nsteps, const float *c,
+                                     const int *status, const double *c_obs, const double *uncer, const unsigned char *mask,
+                                     int obs_per_chain, const double *q, double *p0, double *chi0, double *row,
+                                     long row_stride, long step_stride, unsigned long long seed, unsigned long long counter,
+                                     long chain0);
 
 /* ---- (7) introspection of the two-tier root search.  The production kernel hands the stacks it cannot treat
  *          faithfully to an exact fallback kernel that runs right behind it inside the same call: a secular

@@ -30,7 +30,7 @@ EXPORTS = (
     "surfdisp_forward_batch_device_events", "surfdisp_events_create", "surfdisp_events_destroy",
     "surfdisp_events_elapsed_ms", "surfdisp_stream_wait_event", "surfdisp_params_to_model_device",
     "surfdisp_params_to_model_thermal_device", "surfdisp_thermal_scratch_bytes",
-    "surfdisp_mcmc_propose_device", "surfdisp_mcmc_accept_device",
+    "surfdisp_mcmc_propose_device", "surfdisp_mcmc_accept_device", "surfdisp_mcmc_propose_tree_device", "surfdisp_mcmc_accept_tree_device",
     "surfdisp_forward_kernels_device", "surfdisp_kernels_workspace_bytes", "surfdisp_workspace_fallback_count", "surfdisp_set_team", "surfdisp_get_team", "surfdisp_get_team2",
     "surfdisp_device_count", "surfdisp_abi_version", "surfdisp_last_error",
     "surfdisp_kernel_name",
@@ -114,6 +114,11 @@ def lib() -> ctypes.CDLL:
     L.surfdisp_mcmc_accept_device.restype = ctypes.c_int
     L.surfdisp_mcmc_accept_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int,
                                               vp, vp, vp, vp, ctypes.c_long, u64, u64, ctypes.c_int, ctypes.c_long]
+    L.surfdisp_mcmc_propose_tree_device.restype = ctypes.c_int
+    L.surfdisp_mcmc_propose_tree_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, u64, u64, vp, ctypes.c_long]
+    L.surfdisp_mcmc_accept_tree_device.restype = ctypes.c_int
+    L.surfdisp_mcmc_accept_tree_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp,
+                                                   ctypes.c_int, vp, vp, vp, vp, ctypes.c_long, ctypes.c_long, u64, u64, ctypes.c_long]
     L.surfdisp_thread_release.restype = None
     L.surfdisp_thread_release.argtypes = []
     L.surfdisp_workspace_fallback_count.restype = ctypes.c_int

@@ -431,7 +431,18 @@ int surfdisp_mcmc_propose_device(void *stream, int C, int N, const double *p, co
                                  const double *step, unsigned long long seed, unsigned long long counter, int reset, double *out, long chain0)
 {
     if (C < 1 || N < 1 || !p || !vmin || !vmax || !step || !out || chain0 < 0) { set_err("surfdisp_mcmc_propose_device: bad argument"); return SURFDISP_ERR_INVALID; }
-    sd::McmcProposeArgs a{C, N, p, vmin, vmax, step, seed, counter, reset ? 1 : 0, out, chain0};
+    sd::McmcProposeArgs a{C, N, p, vmin, vmax, step, seed, counter, reset ? 1 : 0, out, chain0, 1};
+    SD_HIP(sd::launch_mcmc_propose(static_cast<hipStream_t>(stream), a));
+    return SURFDISP_SUCCESS;
+}
+
+int surfdisp_mcmc_propose_tree_device(void *stream, int C, int N, int depth, const double *p, const double *vmin, const double *vmax,
+                                      const double *step, unsigned long long seed, unsigned long long counter, double *out, long chain0)
+{
+    if (C < 1 || N < 1 || depth < 1 || depth > sd::SD_MCMC_MAX_DEPTH || !p || !vmin || !vmax || !step || !out || chain0 < 0) {
+        set_err("surfdisp_mcmc_propose_tree_device: bad argument (1 <= depth <= 4)"); return SURFDISP_ERR_INVALID;
+    }
+    sd::McmcProposeArgs a{C, N, p, vmin, vmax, step, seed, counter, 0, out, chain0, depth};
     SD_HIP(sd::launch_mcmc_propose(static_cast<hipStream_t>(stream), a));
     return SURFDISP_SUCCESS;
 }
@@ -444,7 +455,22 @@ int surfdisp_mcmc_accept_device(void *stream, int C, int N, int P, const float *
     if (C < 1 || N < 1 || P < 1 || !c || !c_obs || !uncer || !mask || !p1 || !p0 || !chi0) {
         set_err("surfdisp_mcmc_accept_device: bad argument"); return SURFDISP_ERR_INVALID;
     }
-    sd::McmcAcceptArgs a{C, N, P, c, status, c_obs, uncer, mask, obs_per_chain ? 1 : 0, p1, p0, chi0, row, row_stride, seed, counter, first ? 1 : 0, chain0};
+    sd::McmcAcceptArgs a{C, N, P, c, status, c_obs, uncer, mask, obs_per_chain ? 1 : 0, p1, p0, chi0, row, row_stride, seed, counter, first ? 1 : 0, chain0, 1, 1, 0};
+    SD_HIP(sd::launch_mcmc_accept(static_cast<hipStream_t>(stream), a));
+    return SURFDISP_SUCCESS;
+}
+
+int surfdisp_mcmc_accept_tree_device(void *stream, int C, int N, int P, int depth, int nsteps, const float *c, const int *status,
+                                     const double *c_obs, const double *uncer, const unsigned char *mask, int obs_per_chain,
+                                     const double *q, double *p0, double *chi0, double *row, long row_stride, long step_stride,
+                                     unsigned long long seed, unsigned long long counter, long chain0)
+{
+    if (C < 1 || N < 1 || P < 1 || depth < 1 || depth > sd::SD_MCMC_MAX_DEPTH || nsteps < 1 || nsteps > depth ||
+        !c || !c_obs || !uncer || !mask || !q || !p0 || !chi0 || chain0 < 0) {
+        set_err("surfdisp_mcmc_accept_tree_device: bad argument (1 <= nsteps <= depth <= 4)"); return SURFDISP_ERR_INVALID;
+    }
+    sd::McmcAcceptArgs a{C, N, P, c, status, c_obs, uncer, mask, obs_per_chain ? 1 : 0, q, p0, chi0, row, row_stride, seed, counter, 0,
+                         chain0, depth, nsteps, step_stride};
     SD_HIP(sd::launch_mcmc_accept(static_cast<hipStream_t>(stream), a));
     return SURFDISP_SUCCESS;
 }

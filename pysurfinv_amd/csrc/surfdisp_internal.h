@@ -105,6 +105,7 @@ struct LayersArgs {
     float *model;          // [C][5][L]
     double *scratch;       // [C][64][2] (vs, qs) of the thermal layer's grid points, or nullptr
 };
+constexpr int SD_MCMC_MAX_DEPTH = 4, SD_MCMC_MAX_NODES = (1 << SD_MCMC_MAX_DEPTH) - 1;
 struct McmcProposeArgs {
     int C, N;
     const double *p;        // [C][N] current parameters
@@ -113,6 +114,7 @@ struct McmcProposeArgs {
     int reset;              // 1: uniform prior draw for every entry (MCinv.reset), 0: bounded Gaussian step
     double *out;            // [C][N]
     long chain0;            // global index of chain 0 of this launch (keys the random streams: a sampler split into chain groups draws what the unsplit one draws)
+    int depth;              // <= 1: one proposal per chain; d > 1: the speculative tree of 2^d - 1 proposals (out [C][2^d-1][N])
 };
 struct McmcAcceptArgs {
     int C, N, P;
@@ -129,6 +131,8 @@ struct McmcAcceptArgs {
     unsigned long long seed, counter;
     int first;              // 1: first row of a chain (always accepted: the start model)
     long chain0;            // global index of chain 0 of this launch
+    int depth, nsteps;      // speculative tree: walk nsteps <= depth steps (depth <= 1: the plain single test)
+    long step_stride;       // doubles between the mcTrack rows of consecutive steps of one chain
 };
 hipError_t launch_mcmc_propose(hipStream_t s, const McmcProposeArgs &a);
 hipError_t launch_mcmc_accept(hipStream_t s, const McmcAcceptArgs &a);

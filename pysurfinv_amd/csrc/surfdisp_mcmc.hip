@@ -33,20 +33,17 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
     return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
 }
 
-// One thread per (chain, parameter): Gaussian step around the current value, redrawn while it falls outside
-// (vmin, vmax), at most 1000 tries, then a uniform draw (brownian.py:20-27 BrownianVar.move; reset = the uniform branch).
-__global__ __launch_bounds__(256) void surfdisp_mcmc_propose_kernel(McmcProposeArgs A)
+// Bounded Gaussian step around x (brownian.py:20-27 BrownianVar.move): redrawn while it falls outside (lo, hi), at most 1000
+// tries (two normals per Philox call), then a uniform draw ("No valid perturb, uniform reset instead!"); reset: the uniform
+// branch at once (MCinv.reset).  node: position in the speculative tree (0 for the plain lock step).
+__device__ __forceinline__ double draw_bounded(double x, double lo, double hi, double s, uint32_t k0, uint32_t k1,
+                                               unsigned long long counter, uint32_t node, long gidx, bool reset)
 {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)A.C * A.N) return;
-    const int n = (int)(idx % A.N);
-    const double x = A.p[idx], lo = A.vmin[n], hi = A.vmax[n], s = A.step[n];
-    const uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
-    const long gidx = idx + A.chain0 * A.N;                             // (chain, parameter) of the whole sampler: the random stream's index
+    const uint32_t chi32 = (uint32_t)(counter >> 32) ^ (node << 20);
     double nv = 0.0;
     bool ok = false;
-    for (uint32_t t = 0; t < 500 && !ok; ++t) {                        // two normals per Philox call: 1000 tries
-        const U4 r = philox4x32_10(U4{(uint32_t)A.counter, (uint32_t)(A.counter >> 32) ^ (t << 8), (uint32_t)gidx, (uint32_t)(gidx >> 32)}, k0, k1);
+    for (uint32_t t = 0; t < 500 && !ok && !reset; ++t) {
+        const U4 r = philox4x32_10(U4{(uint32_t)counter, chi32 ^ (t << 8), (uint32_t)gidx, (uint32_t)(gidx >> 32)}, k0, k1);
         const double u1 = u53(r.x, r.y), u2 = u53(r.z, r.w);
         const double rad = sqrt(-2.0 * log(u1));
         double sn, cs;
@@ -55,25 +52,51 @@ __global__ __launch_bounds__(256) void surfdisp_mcmc_propose_kernel(McmcProposeA
         ok = (nv < hi) && (nv > lo);
         if (!ok) { nv = x + s * rad * sn; ok = (nv < hi) && (nv > lo); }
     }
-    if (!ok || A.reset) {                                              // "No valid perturb, uniform reset instead!" / MCinv.reset
-        const U4 r = philox4x32_10(U4{(uint32_t)A.counter, (uint32_t)(A.counter >> 32) ^ 0x00ffff00u, (uint32_t)gidx, (uint32_t)(gidx >> 32)}, k0, k1);
+    if (!ok) {
+        const U4 r = philox4x32_10(U4{(uint32_t)counter, chi32 ^ 0x00ffff00u, (uint32_t)gidx, (uint32_t)(gidx >> 32)}, k0, k1);
         nv = lo + (hi - lo) * u53(r.x, r.y);
     }
-    A.out[idx] = nv;
+    return nv;
 }
 
-// One thread per chain: misfit of the proposal against the chain's observations, accept rule, state update, mcTrack row.
-__global__ __launch_bounds__(256) void surfdisp_mcmc_accept_kernel(McmcAcceptArgs A)
+// One thread per (chain, parameter).  depth <= 1: one proposal, out [C][N].  depth d > 1 (speculative sampler): the binary
+// tree of the next d accept / reject outcomes - node k's proposal is drawn from the state its branch would be in (node 0:
+// the chain's state; child 2k+1 "accepted": the proposal of k; child 2k+2 "rejected": the state of k), out [C][2^d - 1][N].
+// Every scalar moves independently (brownian.py), so a thread builds the whole tree of its own parameter.
+__global__ __launch_bounds__(256) void surfdisp_mcmc_propose_kernel(McmcProposeArgs A)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= A.C) return;
-    const int P = A.P, N = A.N;
-    const float *cp = A.c + (size_t)c * P;
-    const size_t ob = A.obs_per_chain ? (size_t)c * P : 0;
-    bool failed = A.status && A.status[c] != 0;
-    double chi = 0.0;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)A.C * A.N) return;
+    const int n = (int)(idx % A.N);
+    const long c = idx / A.N;
+    const double lo = A.vmin[n], hi = A.vmax[n], s = A.step[n];
+    const uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
+    const long gidx = idx + A.chain0 * A.N;                             // (chain, parameter) of the whole sampler: the random stream's index
+    const int M = A.depth > 1 ? (1 << A.depth) - 1 : 1;
+    double S[SD_MCMC_MAX_NODES];
+    S[0] = A.p[idx];
+    // fully unrolled: every index of S is a compile-time constant.  (With a run-time index the register array is written
+    // through s_set_gpr_idx BEFORE the bounds test selects the result - hipcc 7.2 speculates the guarded stores - and the
+    // out-of-range writes of the nodes 7..14 of a depth-4 tree land in the neighbouring live registers, the output pointer
+    // among them: a memory fault, found on the first depth-4 run.)
+#pragma unroll
+    for (int k = 0; k < SD_MCMC_MAX_NODES; ++k) {
+        if (k < M) {
+            const double x = S[k];
+            const double nv = draw_bounded(x, lo, hi, s, k0, k1, A.counter, (uint32_t)k, gidx, A.reset != 0);
+            A.out[((size_t)c * M + k) * A.N + n] = nv;
+            if (2 * k + 2 < SD_MCMC_MAX_NODES) { S[2 * k + 1] = nv; S[2 * k + 2] = x; }
+        }
+    }
+}
+
+// misfit of one predicted curve against a chain's observations: (misfit, chi-square with the reference's clamp, L)
+__device__ __forceinline__ void misfit_of(const McmcAcceptArgs &A, const float *cp, bool failed, size_t ob,
+                                          double &mis, double &chi, double &L)
+{
+    chi = 0.0;
     int cnt = 0;
-    for (int k = 0; k < P; ++k) {
+    for (int k = 0; k < A.P; ++k) {
         const double v = (double)cp[k];
         if (v < 0.01) failed = true;                                   // models.py:29-33
         if (A.mask[ob + k]) {
@@ -82,30 +105,54 @@ __global__ __launch_bounds__(256) void surfdisp_mcmc_accept_kernel(McmcAcceptArg
             ++cnt;
         }
     }
-    double mis = sqrt(chi / (double)cnt);                              // point.py:27-31
+    mis = sqrt(chi / (double)cnt);                                     // point.py:27-31
     if (!(chi < 50.0)) chi = sqrt(chi * 50.0);
-    double L = exp(-0.5 * chi);
+    L = exp(-0.5 * chi);
     if (failed) { mis = 88888.0; chi = 88888.0; L = 0.0; }             // point.py:20-21
-    const double chi0 = A.chi0[c];
-    bool acc;
-    if (A.first) acc = true;                                           // a chain's first row: the start model itself
-    else if (chi < chi0) acc = true;                                   // point.py:34-37
-    else {
-        const U4 r = philox4x32_10(U4{(uint32_t)A.counter, (uint32_t)(A.counter >> 32) ^ 0x00aaaa00u, (uint32_t)(A.chain0 + c), (uint32_t)((unsigned long long)(A.chain0 + c) >> 32)}, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-        const double u = u53(r.x, r.y);
-        acc = u > 1.0 - exp(-(chi - chi0) / 2.0);
-    }
-    const double *p1 = A.p1 + (size_t)c * N;
+}
+
+// One thread per chain: misfit of the proposal against the chain's observations, accept rule, state update, mcTrack row.
+// depth d > 1: the chain walks the tree of surfdisp_mcmc_propose_kernel for nsteps <= d steps - at node k the usual test of
+// proposal k against the current state, then child 2k+1 (accepted) or 2k+2 - one mcTrack row per step, step_stride doubles
+// apart.  Every proposal was drawn from the state the chain is in when it is tested, so the chain is the plain sampler's.
+__global__ __launch_bounds__(256) void surfdisp_mcmc_accept_kernel(McmcAcceptArgs A)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= A.C) return;
+    const int P = A.P, N = A.N;
+    const int M = A.depth > 1 ? (1 << A.depth) - 1 : 1;
+    const int nsteps = A.depth > 1 ? A.nsteps : 1;
+    const size_t ob = A.obs_per_chain ? (size_t)c * P : 0;
+    const unsigned long long gc = (unsigned long long)(A.chain0 + c);
     double *p0 = A.p0 + (size_t)c * N;
-    if (A.row) {
-        double *row = A.row + (size_t)c * A.row_stride;
-        row[0] = mis; row[1] = L; row[2] = acc ? 1.0 : 0.0;
-        for (int n = 0; n < N; ++n) row[3 + n] = p1[n];
+    double chi0 = A.chi0[c];
+    int node = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const size_t q = (size_t)c * M + node;                         // this step's proposal: stack q of the batched solve
+        double mis, chi, L;
+        misfit_of(A, A.c + q * P, A.status && A.status[q] != 0, ob, mis, chi, L);
+        bool acc;
+        if (A.first) acc = true;                                       // a chain's first row: the start model itself
+        else if (chi < chi0) acc = true;                               // point.py:34-37
+        else {
+            const U4 r = philox4x32_10(U4{(uint32_t)A.counter, (uint32_t)(A.counter >> 32) ^ 0x00aaaa00u ^ ((uint32_t)s << 28),
+                                          (uint32_t)gc, (uint32_t)(gc >> 32)}, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+            const double u = u53(r.x, r.y);
+            acc = u > 1.0 - exp(-(chi - chi0) / 2.0);
+        }
+        const double *p1 = A.p1 + q * N;
+        if (A.row) {
+            double *row = A.row + (size_t)c * A.row_stride + (size_t)s * A.step_stride;
+            row[0] = mis; row[1] = L; row[2] = acc ? 1.0 : 0.0;
+            for (int n = 0; n < N; ++n) row[3 + n] = p1[n];
+        }
+        if (acc) {
+            for (int n = 0; n < N; ++n) p0[n] = p1[n];
+            chi0 = chi;
+        }
+        node = acc ? 2 * node + 1 : 2 * node + 2;
     }
-    if (acc) {
-        for (int n = 0; n < N; ++n) p0[n] = p1[n];
-        A.chi0[c] = chi;
-    }
+    A.chi0[c] = chi0;
 }
 
 hipError_t launch_mcmc_propose(hipStream_t s, const McmcProposeArgs &a)

@@ -32,7 +32,7 @@ def summary_columns(n_params, n_periods):
 
 def run_grid(model_batch, lons, lats, periods, c_obs, uncer, chains_per_point, chainL, outdir=None,
              rank=0, world=1, device="cuda:0", seed=0, forward=None, isgood=None, fast_scan=False,
-             writer_threads=4, keep_tracks=True, local_info=None, chain_groups=None):
+             writer_threads=4, keep_tracks=True, local_info=None, chain_groups=None, spec_depth=None):
     """Invert the points owned by ``rank``.
 
     model_batch : layers_batch.Model1DBatch (one setting for the grid)
@@ -43,6 +43,8 @@ def run_grid(model_batch, lons, lats, periods, c_obs, uncer, chains_per_point, c
     c_obs, uncer: [n_points, P] (NaN / non-positive uncertainty = masked period)
     chain_groups: None (the sampler's default: two groups of chains on two streams from 4 096 chains per rank on,
                   ``MetropolisBatch.chain_groups``) or their number; the random numbers of every chain do not depend on it
+    spec_depth  : None (the sampler's default: speculative lock steps of depth 3 / 2 for up to 292 / 682 chains per rank,
+                  ``MetropolisBatch.auto_spec_depth``) or the depth (1 = one step per forward solve)
     Returns dict(points=(lo, hi), mcTrack=[n_local, chains*chainL, 3+N] or None, summaries=[n_points, 6+2N+P]
     (every rank holds all rows, point order), columns, elapsed (sampling + summaries + gather, this rank),
     elapsed_write, report).  ``report`` carries the MAX over ranks of ``elapsed`` and the summed counters."""
@@ -75,7 +77,7 @@ def run_grid(model_batch, lons, lats, periods, c_obs, uncer, chains_per_point, c
         mc = MetropolisBatch(model_batch.spec, model_batch.to_model, periods, rep(c_obs), rep(uncer),
                              device=device, seed=seed + 7919 * rank, forward=forward, isgood=isgood, fast_scan=fast_scan,
                              local_rows=local_rows)
-        tracks_dev = mc.run_points(n_local, chains_per_point, chainL, on_device=True, groups=chain_groups).reshape(n_local, chains_per_point * chainL, -1)
+        tracks_dev = mc.run_points(n_local, chains_per_point, chainL, on_device=True, groups=chain_groups, spec_depth=spec_depth).reshape(n_local, chains_per_point * chainL, -1)
         first_chain = torch.arange(n_local, device=dev) * chains_per_point     # observation row of each point
         summ = mc.summarise_points(tracks_dev, first_chain)
         n_forward = mc.n_forward

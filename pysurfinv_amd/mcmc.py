@@ -49,7 +49,7 @@ class ChainGroups:
         for g in range(self.G):
             lo, hi = self.bounds[g], self.bounds[g + 1]
             ch = copy.copy(mc)                                  # shares spec, proposer (bounds, steps, seed), periods, to_model
-            ch._plan, ch._fz, ch.event_ring, ch._ev_i, ch.n_forward, ch._groups = None, None, None, 0, 0, {}
+            ch._plan, ch._fz, ch.event_ring, ch._ev_i, ch.n_forward, ch._groups, ch._plans = None, None, None, 0, 0, {}, {}
             if mc.c_obs.ndim == 2:
                 if mc.c_obs.shape[0] != self.C:
                     raise ValueError(f"{self.C} chains against {mc.c_obs.shape[0]} rows of observations")
@@ -219,7 +219,13 @@ class MetropolisBatch:
         from .forward import BatchPlan
         C, _, L = model.shape
         if self._plan is None or (self._plan.B, self._plan.L) != (C, L):
-            self._plan = BatchPlan(C, L, self.periods.numel(), device=self.device)
+            # (the speculative lock step alternates between C and C * (2^d - 1) stacks: keep a plan per size)
+            plans = self.__dict__.setdefault("_plans", {})
+            if (C, L) not in plans:
+                if len(plans) >= 4:
+                    plans.clear()
+                plans[(C, L)] = BatchPlan(C, L, self.periods.numel(), device=self.device)
+            self._plan = plans[(C, L)]
         ev = None
         if self.event_ring is not None:
             ev = self.event_ring.slot(self._ev_i)
@@ -261,6 +267,56 @@ class MetropolisBatch:
                                                      1 if st["c_obs"].ndim == 2 else 0, ptr(p1), ptr(p), ptr(st["chi"]),
                                                      rowp, int(row_stride), pr.seed_int, counter, 1 if first else 0,
                                                      self._chain0))
+        return p
+
+    SPEC_MAX_STACKS = 2048          # stacks per speculative lock step: a 64-lane team = one wavefront each, the chip holds 4 096
+
+    def auto_spec_depth(self, C):
+        """Depth of the speculative lock step the fused path takes by default: the deepest tree (<= 3) whose
+        C * (2^d - 1) stacks stay within ``SPEC_MAX_STACKS`` - a lock step of so few stacks is one wavefront per stack walking
+        its periods one after the other on a mostly idle chip, and costs the same 0.9-1.0 ms for 100 stacks as for 700
+        (100 chains x 96 layers: 0.96 ms per step plain, 0.345 with d = 3, 0.31 with d = 4 at 4.1 forward solves per step;
+        scripts/time_speculative.py); 1 from 683 chains on, and 1 where the (stack, period) decomposition fills the chip
+        instead (``independent``: 0.24 ms per step plain, 0.29 with d = 3)."""
+        if self.independent is True or (self.independent == "auto" and C < self.AUTO_INDEP_CHAINS):
+            return 1
+        for d in (3, 2):
+            if C * ((1 << d) - 1) <= self.SPEC_MAX_STACKS:
+                return d
+        return 1
+
+    def fused_tree_step(self, p, depth, nsteps, row=None, row_stride=0, row_offset=0, step_stride=0, counter=None):
+        """``nsteps`` <= ``depth`` Metropolis steps of every chain from ONE batched solve (speculative / "prefetching"
+        Metropolis on the device: ``surfdisp_mcmc_propose_tree_device`` lays out the binary tree of the next ``depth``
+        accept / reject outcomes, 2^depth - 1 proposals per chain, each drawn from the state its branch would be in; all go
+        through one forward solve; ``surfdisp_mcmc_accept_tree_device`` walks the tree with the usual test).  Every
+        proposal is drawn from and tested against the state the chain is in at that step: the chain is distributed exactly
+        as with ``fused_step``.  mcTrack rows of the steps ``step_stride`` doubles apart, the first at ``row_offset``."""
+        import ctypes
+        torch = self.torch
+        C, N = p.shape
+        M = (1 << int(depth)) - 1
+        st = self._fused_buffers(C)
+        if st.get("M") != M:
+            st["M"] = M
+            st["q"] = torch.empty((C, M, N), dtype=torch.float64, device=self.device)
+            st["qrows"] = torch.arange(C, device=self.device).repeat_interleave(M) if self.local_rows is not None else None
+        L = _lib.lib()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+        pr = self.proposer
+        if counter is None:
+            self._counter += 1
+            counter = self._counter
+        rowp = ctypes.c_void_p(row.data_ptr() + 8 * int(row_offset)) if row is not None else ctypes.c_void_p(0)
+        with torch.cuda.device(self.device):
+            _lib.check(L.surfdisp_mcmc_propose_tree_device(stream, C, N, int(depth), ptr(p), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step),
+                                                           pr.seed_int, counter, ptr(st["q"]), self._chain0))
+            c, status = self._solve_raw(st["q"].view(C * M, N), rows=st["qrows"])
+            _lib.check(L.surfdisp_mcmc_accept_tree_device(stream, C, N, int(self.periods.numel()), int(depth), int(nsteps),
+                                                          ptr(c), ptr(status), ptr(st["c_obs"]), ptr(st["uncer"]), ptr(st["mask8"]),
+                                                          1 if st["c_obs"].ndim == 2 else 0, ptr(st["q"]), ptr(p), ptr(st["chi"]),
+                                                          rowp, int(row_stride), int(step_stride), pr.seed_int, counter, self._chain0))
         return p
 
     # ------------------------------------------------------------------ chain groups
@@ -331,7 +387,7 @@ class MetropolisBatch:
         return new
 
     # ------------------------------------------------------------------ the sampler
-    def run(self, n_chains, chainL, init_first=True, priori=False, _init_mask=None, spec_depth=1, fused=None, groups=None):
+    def run(self, n_chains, chainL, init_first=True, priori=False, _init_mask=None, spec_depth=None, fused=None, groups=None):
         """Advance ``n_chains`` chains for ``chainL`` steps each (= MCinvMP with runN = n_chains*chainL).
 
         Returns mcTrack float64 [n_chains, chainL, 3+N]; chain 0 starts at the initial model when
@@ -344,24 +400,42 @@ class MetropolisBatch:
         chain then walks the tree with the usual accept rule: d Metropolis steps per lock step.
         Every proposal is still drawn from q(current state, .) and tested against the current state,
         so the chain is distributed exactly as with d = 1; only the order in which random numbers are
-        consumed differs (the exact-replay path of the reference trace uses d = 1).
+        consumed differs (the exact-replay path of the reference trace uses d = 1).  Default (None): on the fused device
+        path ``auto_spec_depth`` (3 for up to 292 chains, 2 up to 682, else 1), on the torch path 1.
 
         ``fused`` (default: whenever ``fused_available()``): the lock step as device kernels around the solver
         (``fused_step``: Philox random numbers keyed by the proposer's seed; same proposal and accept distributions).
         ``groups``: chain groups of the fused path (``chain_groups``; every chain's random numbers do not depend on it)."""
-        if spec_depth > 1 and not priori:
-            return self._run_speculative(n_chains, chainL, init_first, _init_mask, int(spec_depth))
         torch = self.torch
         C, N = int(n_chains), self.spec.n
-        track = torch.zeros((C, chainL, 3 + N), dtype=torch.float64, device=self.device)
         if fused is None:
             fused = self.fused_available() and not priori
+        if spec_depth is None:
+            spec_depth = self.auto_spec_depth(C) if (fused and groups in (None, 1)) else 1
+        spec_depth = int(spec_depth)
+        if spec_depth > 1 and not priori and not fused:
+            return self._run_speculative(n_chains, chainL, init_first, _init_mask, spec_depth)
+        track = torch.zeros((C, chainL, 3 + N), dtype=torch.float64, device=self.device)
         if fused:
             # propose / accept kernels around the solver: mcTrack rows are written by the accept kernel itself
             p = self._start(C, init_first, _init_mask).contiguous().clone()
             stride = chainL * (3 + N)
-            cg = self.chain_groups(C, groups)
+            cg = self.chain_groups(C, groups) if spec_depth <= 1 else None
             base = self._counter
+            if cg is None and spec_depth > 1:
+                # speculative lock steps: the first row is the start model itself, then spec_depth steps per batched solve
+                if spec_depth > 4:
+                    raise ValueError("spec_depth of the fused path is at most 4")
+                self.fused_step(p, row=track, row_stride=stride, row_offset=0, first=True, counter=base + 1)
+                i, n = 1, 1
+                while i < chainL:
+                    ns = min(spec_depth, chainL - i)
+                    n += 1
+                    self.fused_tree_step(p, spec_depth, ns, row=track, row_stride=stride, row_offset=i * (3 + N),
+                                         step_stride=3 + N, counter=base + n)
+                    i += ns
+                self._counter = base + n
+                return track
             if cg is not None:
                 cg.fork()
             for i in range(chainL):
@@ -462,14 +536,14 @@ class MetropolisBatch:
                 i += 1
         return track
 
-    def run_points(self, n_points, chains_per_point, chainL, on_device=False, groups=None):
+    def run_points(self, n_points, chains_per_point, chainL, on_device=False, groups=None, spec_depth=None):
         """MCinvMP for n_points at once: chain index = point * chains_per_point + k; chain k = 0 of
         every point starts at the initial model, the others at prior draws (point.py:95-99).
         Returns float64 [n_points, chains_per_point, chainL, 3+N] (numpy, or the device tensor)."""
         torch = self.torch
         C = n_points * chains_per_point
         first = (torch.arange(C, device=self.device) % chains_per_point) == 0
-        tr = self.run(C, chainL, init_first=False, _init_mask=first, groups=groups).reshape(n_points, chains_per_point, chainL, -1)
+        tr = self.run(C, chainL, init_first=False, _init_mask=first, groups=groups, spec_depth=spec_depth).reshape(n_points, chains_per_point, chainL, -1)
         return tr if on_device else tr.cpu().numpy()
 
     def summarise_points(self, track, obs_rows):

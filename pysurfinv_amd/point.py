@@ -54,11 +54,13 @@ class Point:
         return float(mis[0]), float(chi[0]), float(L[0])
 
     def MCinvMP(self, outdir="MCtest", pid=None, runN=50000, chainL=1000, nprocess=None, seed=42,
-                priori=False, isgood=None, verbose=True, spec_depth=1, independent=False, fast_scan=False):
+                priori=False, isgood=None, verbose=True, spec_depth=None, independent=False, fast_scan=False):
         """``runN // chainL`` chains of ``chainL`` steps each, the first one started at the initial model
         (point.py:91-125); writes ``{outdir}/{pid}.npz`` and returns the mcTrack array [runN, 3 + N].
         ``independent="auto"``: the period-parallel root search while the chains are too few to fill the chip (3 x faster
-        lock steps for 100 chains; see ``MetropolisBatch``) - opt-in, the default is the reference's period walk."""
+        lock steps for 100 chains; see ``MetropolisBatch``) - opt-in, the default is the reference's period walk.
+        ``spec_depth``: None = the sampler's default (speculative lock steps on the device path: three Metropolis steps per
+        batched solve for up to 292 chains, same chain distribution; ``MetropolisBatch.auto_spec_depth``), 1 = one step per solve."""
         if priori and outdir.split("_")[-1] != "priori":
             outdir = "_".join((outdir, "priori"))
         pid = self.pid if pid is None else pid

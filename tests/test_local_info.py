@@ -106,7 +106,7 @@ def test_grid_with_local_info_is_the_same_for_any_chain_grouping():
     for g in (1, 2, 3):
         m = Model1DBatch(SETTINGS["hyb"], device="cuda:0", local_keys=keys)
         r = grid.run_grid(m, np.arange(npts), np.zeros(npts), periods, c_obs, unc, chains, chainL, device="cuda:0", seed=5,
-                          local_info=table, chain_groups=g)
+                          local_info=table, chain_groups=g, spec_depth=1)
         out.append((r["mcTrack"], r["summaries"]))
     assert out[0][0].shape == (npts, chains * chainL, 3 + m.spec.n)
     for tr, sm in out[1:]:

@@ -132,12 +132,12 @@ def test_gpu_sampler_statistics_match_reference_trace():
     mb = Model1DBatch(CONT, device="cuda:0")
     mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], G["trace/c_obs"], G["trace/uncer"],
                          device="cuda:0", seed=1)
-    tr = mc.run(512, 80).cpu().numpy()
+    tr = mc.run(512, 80).cpu().numpy()                               # (default: speculative lock steps of depth 2 for 512 chains)
     ref = G["trace/mcTrack"]
     acc, acc_ref = tr[:, 1:, 2].mean(), ref[np.arange(240) % 80 != 0, 2].mean()
     assert abs(acc - acc_ref) < 0.15, (acc, acc_ref)
     assert tr[:, :, 0].min() <= ref[:, 0].min() * 1.05
-    assert mc.n_forward == 512 * 80
+    assert mc.auto_spec_depth(512) == 2 and mc.n_forward == 512 * (1 + 3 * 40)      # 79 steps = 40 lock steps of 3 proposals
 
 
 def test_speculative_sampler_walks_a_consistent_chain():
@@ -320,7 +320,7 @@ def test_fused_run_records_consistent_rows():
     mb = Model1DBatch(CONT, device=dev)
     kw = dict(device=dev, seed=4)
     mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], G["trace/c_obs"], G["trace/uncer"], **kw)
-    tr = mc.run(256, 40)
+    tr = mc.run(256, 40, spec_depth=1)
     assert mc.n_forward == 256 * 40
     for k in (0, 1, 17, 39):
         mis, _, Lk = mc.misfit(tr[:, k, 3:].contiguous())
@@ -330,6 +330,61 @@ def test_fused_run_records_consistent_rows():
     tr2 = mc2.run(256, 40, fused=False)
     a1, a2 = float(tr[:, 1:, 2].mean()), float(tr2[:, 1:, 2].mean())
     assert abs(a1 - a2) < 0.05, (a1, a2)
+
+
+def _check_chains(tr, mb, mc, rows=(0, 1, 2, 3, 17, 38, 39)):
+    """mcTrack [C, chainL, 3+N]: recorded misfits are the misfits of the recorded proposals; every proposal lies within a
+    few step widths of the state it was drawn from (the last accepted row before it) and inside the bounds."""
+    for k in rows:
+        mis, _, Lk = mc.misfit(tr[:, k, 3:].contiguous())
+        assert float((mis - tr[:, k, 0]).abs().max()) < 1e-9 and float((Lk - tr[:, k, 1]).abs().max()) < 1e-12, k
+    t = tr.cpu().numpy()
+    step = np.asarray(mb.spec.step)
+    assert (t[:, :, 3:] > mb.spec.vmin).all() and (t[:, :, 3:] < mb.spec.vmax).all() and (t[:, 0, 2] == 1).all()
+    for c in range(0, t.shape[0], 23):
+        state = t[c, 0, 3:]
+        for i in range(1, t.shape[1]):
+            assert (np.abs(t[c, i, 3:] - state) < 8 * step).all(), (c, i)
+            if t[c, i, 2] == 1:
+                state = t[c, i, 3:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [None, 2, 4])
+def test_fused_speculative_lock_steps(depth):
+    """The device path's speculative lock step (surfdisp_mcmc_propose_tree_device / _accept_tree_device): depth steps per
+    batched solve of C * (2^depth - 1) proposals.  Rows form valid chains (every proposal drawn around the state the chain
+    was in, recorded misfit = misfit of the recorded proposal), acceptance as the plain sampler's, also with a chain length
+    that is not a multiple of the depth and with per-chain observations."""
+    dev = torch.device("cuda:0")
+    mb = Model1DBatch(CONT, device=dev)
+    C, chainL = 256, 40
+    rng = np.random.default_rng(3)
+    c_obs = np.tile(G["trace/c_obs"], (C, 1)) * (1 + 0.01 * rng.standard_normal((C, 1)))
+    unc = np.tile(G["trace/uncer"], (C, 1))
+    mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], c_obs, unc, device=dev, seed=4)
+    tr = mc.run(C, chainL, spec_depth=depth)
+    d = depth or 3
+    assert mc.auto_spec_depth(C) == 3 and mc.auto_spec_depth(293) == 2 and mc.auto_spec_depth(683) == 1
+    assert mc.n_forward == C * (1 + ((1 << d) - 1) * -(-(chainL - 1) // d))
+    _check_chains(tr, mb, mc)
+    mc1 = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], c_obs, unc, device=dev, seed=4)
+    tr1 = mc1.run(C, chainL, spec_depth=1)
+    assert torch.equal(tr[:, 0], tr1[:, 0])                            # same start models, same first rows
+    a, a1 = float(tr[:, 1:, 2].mean()), float(tr1[:, 1:, 2].mean())
+    assert abs(a - a1) < 0.04, (a, a1)
+    assert abs(float(tr[:, -1, 0].median()) / float(tr1[:, -1, 0].median()) - 1) < 0.3
+    # depth 1 through the tree entries is the plain lock step, bit for bit (same random streams)
+    if depth == 2:
+        mcA = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], c_obs, unc, device=dev, seed=9)
+        mcB = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], c_obs, unc, device=dev, seed=9)
+        pA = mcA.reset(C).contiguous(); pB = pA.clone()
+        rA = torch.zeros((C, 3 + mb.spec.n), dtype=torch.float64, device=dev); rB = torch.zeros_like(rA)
+        mcA.fused_step(pA, first=True); mcB.fused_step(pB, first=True)
+        for _ in range(3):
+            mcA.fused_step(pA, row=rA, row_stride=3 + mb.spec.n)
+            mcB.fused_tree_step(pB, 1, 1, row=rB, row_stride=3 + mb.spec.n, step_stride=3 + mb.spec.n)
+            assert torch.equal(pA, pB) and torch.equal(rA, rB)
 
 
 @pytest.mark.gpu
@@ -348,13 +403,13 @@ def test_chain_groups_do_not_change_the_chains():
     for groups in (1, 2, 3):
         mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], c_obs, unc, device=dev, seed=21)
         first = (torch.arange(C, device=dev) % 50) == 0
-        tr = mc.run(C, chainL, init_first=False, _init_mask=first, groups=groups)
+        tr = mc.run(C, chainL, init_first=False, _init_mask=first, groups=groups, spec_depth=1)
         torch.cuda.synchronize()
         assert mc.n_forward == C * chainL and mc._counter == chainL
         assert (mc.chain_groups(C, groups) is None) == (groups == 1)
         tracks.append(tr.cpu().numpy())
         # a second run continues the counter: other random numbers
-        tr2 = mc.run(C, chainL, init_first=False, _init_mask=first, groups=groups)
+        tr2 = mc.run(C, chainL, init_first=False, _init_mask=first, groups=groups, spec_depth=1)
         assert mc._counter == 2 * chainL and not np.array_equal(tr2.cpu().numpy()[:, 1:], tracks[-1][:, 1:])
     assert np.array_equal(tracks[0], tracks[1]) and np.array_equal(tracks[0], tracks[2])
     acc = tracks[0][:, 1:, 2].mean()
