@@ -248,6 +248,26 @@ def leg_roofline(leg, live_ms, alg_bytes_per_launch, kernel_prefix="surfdisp_pha
     return roof
 
 
+def chip_level_share(leg, kernels, step_ms):
+    """VALU issue share of a step in which several kernels share the chip (the two root searches, group-velocity and
+    ellipticity kernels of a joint solve): the named kernels' instructions (the leg's PMC pass) / the step's duration."""
+    tfile = os.path.join(ROOT, "profiles", f"traffic_{leg}.json")
+    try:
+        tj = json.load(open(tfile))["kernels"]
+        used = {n: tj[n] for n in kernels if n in tj and "valu_wave_instructions" in tj[n]}
+        if not used or step_ms <= 0:
+            return None
+        step_s = step_ms * 1e-3
+        instr = sum(v["valu_wave_instructions"] for v in used.values())
+        issue = sum(v["valu_issue_frac_measured_costs"] * v["kernel_cycles"] / CLOCK_HZ for v in used.values()
+                    if "valu_issue_frac_measured_costs" in v)
+        return {"kernels": sorted(used), "step_ms": step_ms, "frac": instr / step_s / VALU_PEAK,
+                "frac_measured_issue_costs": issue / step_s,
+                "note": "VALU wave-instructions of the listed kernels (one launch each per step) / the step's duration"}
+    except Exception as e:
+        return {"note": f"profiles/traffic_{leg}.json unreadable: {e}"}
+
+
 # ------------------------------------------------------------------------------------------------ workloads
 def workload_forward(rt, args):
     torch = rt.torch
@@ -547,6 +567,12 @@ def workload_c5(rt, args, steps=None, warmup=None):
     out = plan.run(st["model"], per, nlay=st["nlay"]); rt.barrier()
     okR, okL = float((out["statusR"] == 0).float().mean()), float((out["statusL"] == 0).float().mean())
     w = rt.world
+    roofR = leg_roofline("c5", kmsR[1], (20 * L + 8 * 20) * B,
+                         team=int(_lib.lib().surfdisp_get_team2(B, L, 20, _lib.KIND_RAYLEIGH | _lib.PIPELINED)))
+    roofL = leg_roofline("c5", kmsL[1], (20 * L + 8 * 20) * B, kernel_prefix="surfdisp_phase_kernel<1,",
+                         team=int(_lib.lib().surfdisp_get_team2(B, L, 20, _lib.KIND_LOVE | _lib.PIPELINED)))
+    roofR["chip_level"] = chip_level_share("c5", [roofR.get("kernel"), roofL.get("kernel"), "surfdisp_ellip_kernel",
+                                                  "surfdisp_group_kernel<2,0>", "surfdisp_group_kernel<1,0>"], t_joint / K * 1e3)
     return {"metric": "joint R+L c+U forward solves/s + sensitivity kernels, 64-layer thermal stacks (BASELINE configs[4])",
             "unit": "solves/s", "value": w * 2 * B * K / t_joint, "n_gpus": w, "steps": K, "scaling": "weak",
             "config": {"workload": "BASELINE configs[4] per GPU: 16384 ThermSeis-derived stacks, joint Rayleigh+Love c+U at 20 "
@@ -559,10 +585,7 @@ def workload_c5(rt, args, steps=None, warmup=None):
                           "love": {"prep": kmsL[0], "phase": kmsL[1], "group_and_finish": kmsL[2]},
                           "how": "HIP events on each plan's own stream; the two streams share the chip, so a kernel's "
                                  "duration includes the time it shares SIMDs with the other wave type's kernels"},
-            "roofline": leg_roofline("c5", kmsR[1], (20 * L + 8 * 20) * B,
-                                     team=int(_lib.lib().surfdisp_get_team2(B, L, 20, _lib.KIND_RAYLEIGH | _lib.PIPELINED))),
-            "roofline_love_root_search": leg_roofline("c5", kmsL[1], (20 * L + 8 * 20) * B, kernel_prefix="surfdisp_phase_kernel<1,",
-                                                      team=int(_lib.lib().surfdisp_get_team2(B, L, 20, _lib.KIND_LOVE | _lib.PIPELINED)))}
+            "roofline": roofR, "roofline_love_root_search": roofL}
 
 
 def main():
