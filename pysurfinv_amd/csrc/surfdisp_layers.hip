@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void surfdisp_layers_kernel(LayersArgs A)
     const int L = A.idesc[2];
     if (idx >= (long)A.C * L) return;
     const int c = (int)(idx / L), i = (int)(idx % L);
-    const int nin = A.idesc[0], ngrid = A.idesc[1], has_ref = A.idesc[3];
+    const int nin = A.idesc[0] < 10 ? A.idesc[0] : 10, ngrid = A.idesc[1], has_ref = A.idesc[3];   // (<= 10 input layers: ztop / Hl below; the host-side descriptor builder enforces it)
     const int *lay_i = A.idesc + 4;                    // 8 ints per input layer
     const int *coef_i = lay_i + 8 * nin;               // 8 slots per input layer
     const int *top_i = coef_i + 8 * nin;               // L ints
