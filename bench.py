@@ -375,7 +375,8 @@ def workload_forward(rt, args):
         "kernel_ms": {"prep": kms[0], "phase": kms[1], "group_and_finish": kms[2],
                       "how": "HIP events recorded on the launch stream around each kernel of the K timed "
                              "one-batch-in-flight steps, read after the closing synchronisation; phase = root search + "
-                             "the (idle) exact fallback launch behind it"},
+                             "the (idle) exact fallback launch behind it; group_and_finish = ellipticity kernel + "
+                             "group-velocity kernel + finish"},
         "roofline": roof,
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -151,7 +151,7 @@ int surfdisp_forward_batch_device_timed(void *stream, int B, int Lmax, const int
 
 /* ---- (5) non-blocking measurement: the caller creates events (surfdisp_events_create), passes
  *          four per call; they are recorded on `stream` before prep, after prep, after the root
- *          search and after group+finish.  Read with surfdisp_events_elapsed_ms once the caller has
+ *          search (and its idle fallback launch) and after ellipticity kernel + group + finish.  Read with surfdisp_events_elapsed_ms once the caller has
  *          synchronised.  bench.py records them inside its timed region. */
 int surfdisp_forward_batch_device_events(void *stream, int B, int Lmax, const int *nlay,
                                          const float *model, int P, const float *per, int kind,

@@ -318,11 +318,11 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     ph.overlap = 0; ph.fast = 0;
     if (ell_k) ph.ratio = w.ratio;                         // ... with its ellipticities in-kernel (marked -1 in hist)
     SD_HIP(sd::launch_phase_exact(s, kind, indep, ph));
+    if (ev) SD_HIP(hipEventRecord(ev[2], s));              // [ev1, ev2] = the root search (+ its idle fallback launch)
     if (ell_k) {
         sd::EllipArgs ea{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.hist, w.nsolved, w.ratio};
         SD_HIP(sd::launch_ellip(s, ea));
     }
-    if (ev) SD_HIP(hipEventRecord(ev[2], s));
 #ifdef SD_WAVECLOCK
     double *gdbg = nullptr;                                // the debug buffer holds wavefront clocks in this build
 #else
