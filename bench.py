@@ -365,8 +365,8 @@ def workload_forward(rt, args):
                    "stacks_per_gpu": B_PER_GPU, "layers": NLAY, "periods": NPER,
                    "wave": "Rayleigh c+U", "scan": "default: every 0.01 km/s grid point, as the reference",
                    "batches_in_flight": NFLIGHT,
-                   "team_lanes": int(_lib.lib().surfdisp_get_team(B_PER_GPU * (2 if NFLIGHT > 1 else 1), NLAY)),
-                   "team_lanes_one_batch_in_flight": int(_lib.lib().surfdisp_get_team(B_PER_GPU, NLAY)),
+                   "team_lanes": int(_lib.lib().surfdisp_get_team2(B_PER_GPU, NLAY, NPER, _lib.KIND_RAYLEIGH | (_lib.PIPELINED if (NFLIGHT > 1 and HINT) else 0))),
+                   "team_lanes_one_batch_in_flight": int(_lib.lib().surfdisp_get_team2(B_PER_GPU, NLAY, NPER, _lib.KIND_RAYLEIGH)),
                    "sharding": f"independent stacks, {world} rank(s), no data-path collective"},
         "solved_fraction": n_ok / (world * B_PER_GPU),
         "stacks_through_exact_fallback": n_fb,

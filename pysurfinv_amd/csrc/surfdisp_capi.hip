@@ -119,14 +119,25 @@ int pick_team(int B, int Lmax, bool need_ratio = true, bool pipelined = false, i
         const long target = 196608L;
         G = 2;
         while (G < 64 && (long)B * G < target) G *= 2;
+        // (r03, with the teams of a wavefront in lock step - profiles/r03b/sweep_team_lockstep.txt: for Rayleigh stacks of
+        // >= 24 layers teams of more than 16 lanes cost more in wasted evaluations than the third and fourth wavefront per
+        // SIMD give back - 8 192 x L64: 1.49 ms with 16 lanes against 1.68 with 32, 8 192 x L30: 0.76 against 0.84 - so
+        // beyond 16 lanes they aim at 131 072 lanes only; and a Rayleigh launch that is alone on the chip never takes
+        // two-lane teams - 131 072 x L10: 2.17 against 3.08 ms)
+        if (kind != SURFDISP_KIND_LOVE && Lmax >= 24 && G > 16) {
+            G = 16;
+            while (G < 64 && (long)B * G < 131072L) G *= 2;
+        }
+        if (kind != SURFDISP_KIND_LOVE && !pipelined && G < 4) G = 4;
     }
     // Love evaluations are cheap (a 2-vector recursion, ~35 instructions per layer against Rayleigh's ~95), so a pass's team
-    // bookkeeping weighs more and wider teams = fewer passes win: never fewer than 8 lanes (65 536 x L10: 0.82 -> 0.70 ms), and
+    // bookkeeping weighs more: never fewer than 4 lanes (8 until the teams of a wavefront went in lock step, which took most of
+    // that bookkeeping away: 65 536 x L10 now 0.65 ms with 4 lanes against 0.70 with 8, 65 536 x L30 1.46 against 1.55), and
     // the caller sizes a Love launch for its own stacks even beside another stream's kernels (forward_device_impl: 16 384 x L64
     // beside the Rayleigh root search of a joint solve, teams of 16 instead of 8: 6.59 -> 6.24 ms); measured with the four-field
-    // Love working stack, scripts/sweep_team.py, profiles/r03a/love_team.txt
-    if (kind == SURFDISP_KIND_LOVE && !g_team_override.load(std::memory_order_relaxed) && !knobs().team && !knobs().team_love && G < 8)
-        G = 8;
+    // Love working stack, scripts/sweep_team.py, profiles/r03a/love_team.txt, profiles/r03b/sweep_team_lockstep.txt
+    if (kind == SURFDISP_KIND_LOVE && !g_team_override.load(std::memory_order_relaxed) && !knobs().team && !knobs().team_love && G < 4)
+        G = 4;
     if (G < 1) G = 1;
     if (G > 64) G = 64;
     int p2 = 1;
