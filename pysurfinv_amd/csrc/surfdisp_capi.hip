@@ -215,7 +215,7 @@ int surfdisp_set_team(int lanes)
     return SURFDISP_SUCCESS;
 }
 
-int surfdisp_get_team(int B, int Lmax) { return pick_team(B, Lmax); }
+int surfdisp_get_team(int B, int Lmax) { return surfdisp_get_team2(B, Lmax, 1, SURFDISP_KIND_RAYLEIGH); }   // a Rayleigh c+U call, no flags
 
 // lanes per stack a launch with these flags would use (kind: 1 | 2 with SURFDISP_PHASE_ONLY / _PIPELINED / _INDEPENDENT
 // OR'd in; P: periods, used by the independent decomposition) - what forward_device_impl computes

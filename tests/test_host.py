@@ -33,18 +33,20 @@ def test_workspace_and_team_heuristics():
     L.surfdisp_set_team(0)
     os.environ.pop("SURFDISP_TEAM", None)
     assert L.surfdisp_get_team(1, 10) == 64              # one stack: a whole wavefront
-    assert L.surfdisp_get_team(1 << 20, 10) == 2         # huge batch: two lanes per stack
+    assert L.surfdisp_get_team(1 << 20, 10) == 4         # huge batch, alone on the chip: four lanes per stack ...
+    assert L.surfdisp_get_team2(1 << 20, 10, 20, _lib.KIND_RAYLEIGH | _lib.PIPELINED) == 2     # ... two beside another batch in flight
+    assert L.surfdisp_get_team2(1 << 20, 10, 20, _lib.KIND_LOVE) == 4                          # Love: never fewer than four
     assert L.surfdisp_get_team(65536, 10) == 4           # the bench workload
     g = L.surfdisp_get_team(1 << 20, 200)                # LDS bound forces wider teams
     assert g >= 8 and 4 * 200 * (256 // g) * 4 <= 80 * 1024
-    # the workgroup's working stacks stay within 44 KB of LDS per 256 lanes (two slots of 6 floats per layer + 24 per team
-    # for Rayleigh c+U calls with teams of >= 4 lanes, which is what surfdisp_get_team describes)
-    for B, Lmax in ((65536, 10), (32768, 30), (65536, 30), (16384, 64), (25600, 96), (4096, 20), (100, 96)):
+    # the workgroup's working stacks stay within 44 KB of LDS per 256 lanes (6 floats per layer + 24 per team; surfdisp_get_team
+    # describes a Rayleigh c+U call), and the launch has at least 196 608 lanes - deep stacks beyond 16 lanes: 131 072
+    for B, Lmax in ((65536, 10), (32768, 30), (65536, 30), (16384, 64), (8192, 64), (8192, 30), (25600, 96), (4096, 20), (100, 96)):
         g = L.surfdisp_get_team(B, Lmax)
-        slots = 2 if g >= 4 else 1
-        assert (slots * 6 * Lmax + 24) * (256 // g) * 4 <= 44 * 1024 or g == 64, (B, Lmax, g)
-        assert B * g >= 196608 or g == 64, (B, Lmax, g)
-    assert L.surfdisp_get_team(32768, 30) == 16 and L.surfdisp_get_team(4096, 20) == 64
+        assert (6 * Lmax + 24) * (256 // g) * 4 <= 44 * 1024 or g == 64, (B, Lmax, g)
+        assert B * g >= (131072 if (Lmax >= 24 and g >= 16) else 196608) or g == 64, (B, Lmax, g)
+    assert L.surfdisp_get_team(32768, 30) == 8 and L.surfdisp_get_team(4096, 20) == 64
+    assert L.surfdisp_get_team(8192, 64) == 16 and L.surfdisp_get_team(8192, 30) == 16 and L.surfdisp_get_team(16384, 30) == 16
     assert L.surfdisp_set_team(3) == _lib.ERR_INVALID
     assert L.surfdisp_set_team(16) == 0 and L.surfdisp_get_team(5, 5) == 16
     L.surfdisp_set_team(0)
@@ -115,5 +117,5 @@ def test_team_introspection_needs_no_device():
     assert L.surfdisp_get_team2(1, 10, 20, R) == 64 and L.surfdisp_get_team2(65536, 10, 20, R) == 4
     assert L.surfdisp_get_team2(65536, 10, 20, R | PIPE) == 2           # three batches in flight: two-lane teams
     assert L.surfdisp_get_team2(25600, 96, 19, R | PH) == 16            # the grid leg (LDS: 8-lane teams would need 74 KB)
-    assert L.surfdisp_get_team2(65536, 10, 20, LV) == 8 and L.surfdisp_get_team2(16384, 64, 20, LV | PIPE) == 16
+    assert L.surfdisp_get_team2(65536, 10, 20, LV) == 4 and L.surfdisp_get_team2(16384, 64, 20, LV | PIPE) == 16
     assert L.surfdisp_get_team2(100, 96, 19, R | PH | IND) <= L.surfdisp_get_team2(100, 96, 19, R | PH)
