@@ -22,6 +22,7 @@ struct EnvKnobs {
     int team_love = 0;            // SURFDISP_TEAM_LOVE (developer knob): lanes per stack of Love root searches only
     size_t overlap_max = 64u * 1024u;   // SURFDISP_OVERLAP_MAX
     size_t lds_budget = 44u * 1024u;    // SURFDISP_LDS_BUDGET (developer knob): root-search LDS per 256 lanes
+    size_t lds_budget_pipelined = 44u * 1024u;   // SURFDISP_LDS_BUDGET_PIPELINED (developer knob): ... of a SURFDISP_PIPELINED launch (64 KB until r03)
     float refine_wtol = 1.2e-3f;  // SURFDISP_WTOL
     float refine_atol = 1.0e-6f;  // SURFDISP_ATOL
     float phimax = 0.7853982f;    // SURFDISP_SCAN_PHASE (fast scan only; developer knob)
@@ -43,7 +44,8 @@ struct EnvKnobs {
         if (const char *e = getenv("SURFDISP_TEAM")) team = atoi(e);
         if (const char *e = getenv("SURFDISP_TEAM_LOVE")) team_love = atoi(e);
         if (const char *e = getenv("SURFDISP_OVERLAP_MAX")) overlap_max = (size_t)atol(e);
-        if (const char *e = getenv("SURFDISP_LDS_BUDGET")) lds_budget = (size_t)atol(e);
+        if (const char *e = getenv("SURFDISP_LDS_BUDGET")) lds_budget = lds_budget_pipelined = (size_t)atol(e);
+        if (const char *e = getenv("SURFDISP_LDS_BUDGET_PIPELINED")) lds_budget_pipelined = (size_t)atol(e);
         if (const char *e = getenv("SURFDISP_WTOL")) refine_wtol = (float)atof(e);
         if (const char *e = getenv("SURFDISP_ATOL")) refine_atol = (float)atof(e);
         if (const char *e = getenv("SURFDISP_SCAN_PHASE")) phimax = (float)atof(e);
@@ -149,9 +151,11 @@ int pick_team(int B, int Lmax, bool need_ratio = true, bool pipelined = false, i
     // SIMD, normally four - a wider team wastes fewer evaluations than a half-empty SIMD costs (scripts/sweep_team.py,
     // profiles/r02e/sweep_team.txt; re-checked on the r03 kernels, every auto choice within 1 % of the best forced size).
     const size_t per256 = 256 / SD_PHASE_BLOCK;        // the budget is per 256 lanes
-    // (a caller that keeps another batch in flight - SURFDISP_PIPELINED, the joint Rayleigh + Love plan - has the other
-    // stream's wavefronts to fill a SIMD: there the narrower team's fewer evaluations win, 64 KB = two workgroups)
-    const size_t budget = pipelined ? (knobs().lds_budget * 16) / 11 : knobs().lds_budget;
+    // (until r03 a caller that keeps another batch in flight - SURFDISP_PIPELINED, the joint Rayleigh + Love plan - got 64 KB =
+    // two workgroups: the other stream's wavefronts fill the SIMDs, and the narrower team's fewer evaluations won)
+    // (r03: with the teams of a wavefront in lock step the wider team wins there too - joint solve of 16 384 x L64, Rayleigh
+    // teams of 16 instead of 8: 5.59 -> 5.32 ms - so the budget is the same 44 KB; SURFDISP_LDS_BUDGET_PIPELINED restores 64 KB)
+    const size_t budget = pipelined ? knobs().lds_budget_pipelined : knobs().lds_budget;
     auto lds_of = [&](int g) { return sd::phase_lds_bytes(Lmax, g, need_ratio && g >= 4, kind) * per256; };
     while (G < 64 && lds_of(G) > budget) G *= 2;
     return G;
@@ -316,7 +320,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     const float wtol = kn.refine_wtol, atol = kn.refine_atol, phimax = kn.phimax;
     sd::PhaseArgs ph{B, Lmax, P, w.mdl, w.nl, per, w.ct, ell_in ? w.ratio : nullptr, w.nsolved, status, wtol, atol,
                      fastscan ? 1 : 0, w.fsafe, (ell_in && use_overlap(Lmax, G)) ? 1 : 0, phimax,
-                     w.ovf, w.fb_count, w.fb_list, kn.balance >= 0 ? kn.balance : (pipelined ? 0 : 1), strict ? 1 : 0};
+                     w.ovf, w.fb_count, w.fb_list, kn.balance >= 0 ? kn.balance : ((pipelined && G < 8) ? 0 : 1), strict ? 1 : 0};
 #ifdef SD_WAVECLOCK
     ph.wclk = reinterpret_cast<unsigned long long *>(g_dbg.load(std::memory_order_relaxed));
 #endif

@@ -964,8 +964,10 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         // The SIMD arbitrates between its wavefronts by priority, then age: left alone, the four wavefronts of a
         // SIMD finish one after the other and the last one runs alone for a seventh of the kernel.  Let a wavefront
         // that is behind (period index of its first team) go first: 2.39 -> 2.15 ms for one bench batch (profiles/r02c).
-        // Not when the caller keeps a second batch in flight (SURFDISP_PIPELINED): there the age order is what lets
-        // the older batch drain while the younger one fills the machine.
+        // Not for narrow teams (< 8 lanes) when the caller keeps a second batch in flight (SURFDISP_PIPELINED): there the age
+        // order lets the older batch drain while the younger one fills the machine (three bench batches in flight: 38.4 M
+        // solves/s without, 37.7 M with).  Wide teams keep it also then: the two root searches of a joint Rayleigh + Love
+        // solve of 64-layer stacks, 5.59 -> 5.23 ms (r03).  SURFDISP_BALANCE=0 / 1 forces it.
         if (!INDEP && A.balance) {
             const int kw = __builtin_amdgcn_readfirstlane(k);
             const int pr = 3 - min(3, (4 * kw) / max(P, 1));
