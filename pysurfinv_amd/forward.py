@@ -253,8 +253,8 @@ class JointPlan:
         self.torch = torch
         self.device = torch.device(device)
         self.order = order or os.environ.get("SURFDISP_JOINT_ORDER", "concurrent")
-        if self.order not in ("concurrent", "rayleigh_first", "love_first"):
-            raise ValueError("order: concurrent | rayleigh_first | love_first")
+        if self.order not in ("concurrent", "concurrent_love", "rayleigh_first", "love_first"):
+            raise ValueError("order: concurrent | concurrent_love | rayleigh_first | love_first")
         self.ray = BatchPlan(B, L, P, device=device)
         self.love = BatchPlan(B, L, P, device=device)
         self.s_ray = torch.cuda.Stream(device=self.device)
@@ -269,7 +269,7 @@ class JointPlan:
             s.wait_stream(cur)                       # inputs were produced on the caller's stream
         evR = events[0] if events[0] is not None else self._ring.slot(0)
         evL = events[1] if events[1] is not None else self._ring.slot(1)
-        conc = self.order == "concurrent"
+        conc = self.order in ("concurrent", "concurrent_love")      # (concurrent_love: the Love kernels are enqueued first)
 
         def ray():
             with torch.cuda.stream(self.s_ray):
@@ -282,7 +282,10 @@ class JointPlan:
         def wait(stream, ev):                        # ev[2]: recorded after the root search of the other solve
             _lib.check(_lib.lib().surfdisp_stream_wait_event(ctypes.c_void_p(stream.cuda_stream), ev[2]))
 
-        if self.order == "love_first":
+        if self.order == "concurrent_love":
+            cL, uL, sL = love()
+            cR, uR, sR = ray()
+        elif self.order == "love_first":
             cL, uL, sL = love()
             wait(self.s_ray, evL)
             cR, uR, sR = ray()
