@@ -53,6 +53,11 @@ def lib_hash():
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
+def src_hash():
+    from pysurfinv_amd import _lib
+    return _lib.source_hash()
+
+
 def cpu_baseline(per, c_gpu, u_gpu):
     """Bounded CPU sample on the host cores (rank 0, N=1 only).  Checker code, timed - never the product.  Also the
     parity figure of the bench batch: its first 1024 stacks through the CPU oracle."""
@@ -234,7 +239,8 @@ def leg_roofline(leg, live_ms, alg_bytes_per_launch, kernel_prefix="surfdisp_pha
                      "profile_kernel_avg_ms": v.get("avg_us", 0.0) / 1e3,
                      "lane_utilisation": v.get("lane_utilisation"), "mean_waves_per_simd": v.get("mean_waves_per_simd"),
                      "pmc_profile": tj.get("round"), "pmc_lib_sha256_16": tj.get("lib_sha256_16"), "this_lib_sha256_16": here,
-                     "pmc_matches_this_build": tj.get("lib_sha256_16") == here})
+                     "pmc_matches_this_build": tj.get("lib_sha256_16") == here,
+                     "pmc_matches_this_source": tj.get("src_sha256_16") == src_hash()})
         if chip is not None and chip[1] > 0:
             n, step_s = int(chip[0]), chip[1] * 1e-3
             issue = (v["valu_issue_frac_measured_costs"] * (v["kernel_cycles"] / CLOCK_HZ) if "valu_issue_frac_measured_costs" in v else None)
@@ -343,6 +349,7 @@ def workload_forward(rt, args):
                                                        if "valu_issue_frac_measured_costs" in v else None),
                          "valu_pmc": v, "pmc_profile": tj.get("round"), "pmc_lib_sha256_16": tj.get("lib_sha256_16"),
                          "this_lib_sha256_16": here, "pmc_matches_this_build": bool(same),
+                         "pmc_matches_this_source": tj.get("src_sha256_16") == src_hash(),   # (a rebuilt binary has another hash, the same sources)
                          "note": "achieved = wave-level VALU instructions per launch (SQ_INSTS_VALU of the committed "
                                  "rocprofv3 --pmc pass named in pmc_profile) / the LIVE duration of the kernel (HIP "
                                  "events on its stream); peak = 1024 SIMDs x 2.4 GHz / 2 cycles per instruction; "

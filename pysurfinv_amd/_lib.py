@@ -142,3 +142,20 @@ def check(rc: int) -> None:
     if rc != SUCCESS:
         msg = lib().surfdisp_last_error().decode(errors="replace")
         raise SurfdispError(f"libsurfdisp_hip error {rc}: {msg}")
+
+
+def source_hash():
+    """sha256 (16 hex digits) over the library's sources (csrc/*.hip, *.h, Makefile, include/surfdisp.h): what a counter
+    profile under profiles/ is tagged with beside the binary's own hash - hipcc's output is not bit-reproducible, so a
+    rebuilt library keeps the source tag while its binary hash changes."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h"))
+                   + [os.path.join(here, "csrc", "Makefile"), os.path.join(os.path.dirname(here), "include", "surfdisp.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

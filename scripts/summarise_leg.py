@@ -100,7 +100,9 @@ def main(tag, leg):
         out_k[k] = e
     with open(os.path.join(ROOT, "pysurfinv_amd", "lib", "libsurfdisp_hip.so"), "rb") as fh:
         lib_hash = hashlib.sha256(fh.read()).hexdigest()[:16]
-    out = {"round": tag, "leg": leg, "lib_sha256_16": lib_hash, "kernels": out_k,
+    sys.path.insert(0, ROOT)
+    from pysurfinv_amd import _lib
+    out = {"round": tag, "leg": leg, "lib_sha256_16": lib_hash, "src_sha256_16": _lib.source_hash(), "kernels": out_k,
            "method": "rocprofv3 --kernel-trace --stats for durations; --pmc in separate passes (scripts/profile_leg.sh); "
                      "FETCH_SIZE/WRITE_SIZE KB->bytes x1024, FETCH_SIZE x2 (gfx950); VALU issue share = SQ_INSTS_VALU x 2 "
                      "cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8); *_frac = counter / SQ_WAVE_CYCLES"}

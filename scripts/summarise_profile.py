@@ -15,6 +15,12 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _source_hash():
+    sys.path.insert(0, ROOT)
+    from pysurfinv_amd import _lib
+    return _lib.source_hash()
 KERNELS = ("surfdisp_prep_kernel", "surfdisp_phase_kernel", "surfdisp_group_kernel", "surfdisp_finish_kernel")
 SIMDS = 1024
 
@@ -96,6 +102,7 @@ def main(tag):
     out = {
         "round": tag,
         "lib_sha256_16": lib_hash,          # bench.py compares it with the library it runs: a stale profile is visible
+        "src_sha256_16": _source_hash(),    # ... and, since hipcc's output is not bit-reproducible, with the sources a rebuilt library came from
         "workload": "B=65536 L=10 P=20 Rayleigh c+U, default (point-by-point) scan, one batch in flight",
         "phase_kernel_hbm_bytes_per_launch": per_kernel.get("surfdisp_phase_kernel", {}).get("total"),
         "per_kernel": per_kernel,

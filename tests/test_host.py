@@ -119,3 +119,17 @@ def test_team_introspection_needs_no_device():
     assert L.surfdisp_get_team2(25600, 96, 19, R | PH) == 16            # the grid leg (LDS: 8-lane teams would need 74 KB)
     assert L.surfdisp_get_team2(65536, 10, 20, LV) == 4 and L.surfdisp_get_team2(16384, 64, 20, LV | PIPE) == 16
     assert L.surfdisp_get_team2(100, 96, 19, R | PH | IND) <= L.surfdisp_get_team2(100, 96, 19, R | PH)
+
+
+def test_committed_counter_profiles_are_of_these_sources():
+    """profiles/traffic_{latest,grid,c5,mcmc}.json - what bench.py's roofline blocks read - carry the hash of the library
+    sources they were measured on (hipcc's binaries are not bit-reproducible, the sources are): a kernel change without a
+    new counter pass fails here instead of shipping a roofline of another build."""
+    import json
+    from pysurfinv_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    here = _lib.source_hash()
+    assert len(here) == 16
+    for leg in ("latest", "grid", "c5", "mcmc"):
+        tj = json.load(open(os.path.join(root, "profiles", f"traffic_{leg}.json")))
+        assert tj.get("src_sha256_16") == here, (leg, tj.get("src_sha256_16"), here)
