@@ -409,7 +409,10 @@ class MetropolisBatch:
         torch = self.torch
         C, N = int(n_chains), self.spec.n
         if fused is None:
-            fused = self.fused_available() and not priori
+            fused = self.fused_available()
+        fused = bool(fused) and not priori                         # a priori run evaluates nothing: the torch loop below
+        if fused and not self.fused_available():
+            raise ValueError("fused=True needs the device proposer, no isgood callback and the HIP forward path")
         if spec_depth is None:
             spec_depth = self.auto_spec_depth(C) if (fused and groups in (None, 1)) else 1
         spec_depth = int(spec_depth)
