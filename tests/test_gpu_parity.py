@@ -767,7 +767,25 @@ def test_entries_may_be_called_from_several_threads(hip):
         except Exception as e:                                   # noqa: BLE001 - reported through the list
             errors.append(("exception", t, repr(e)))
 
-    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    # ... and two more threads push LARGE host-buffer calls through (chunked over each thread's own three streams and
+    # grow-only device buffer), then give their buffers back
+    big = synth.synth_models(70000, 10, seed=77)
+    big_serial = hip.forward_batch(big, per, 2)
+
+    def big_worker(t):
+        try:
+            from pysurfinv_amd import _lib
+            for it in range(3):
+                c, u, st = hip.forward_batch(big, per, 2)
+                if not (np.array_equal(c, big_serial[0]) and np.array_equal(u, big_serial[1], equal_nan=True)
+                        and np.array_equal(st, big_serial[2])):
+                    errors.append(("big batch", t, it))
+            _lib.lib().surfdisp_thread_release()
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(("exception", t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)] + \
+              [threading.Thread(target=big_worker, args=(t,)) for t in range(2)]
     for th in threads:
         th.start()
     for th in threads:
