@@ -428,12 +428,12 @@ class Model1DBatch:
         return torch.where(H < H_LOWER, torch.full_like(N, -1), N), H     # -1: layer skipped (models.py:80-81)
 
     # ------------------------------------------------------------------ public
-    def seis_prop_layers(self, params, rows=None):
-        """(h, vs, vp, rho, qs, qp) float64 [B, Lmax] padded with zeros, and nlay[B] -
-        ``Model1D.seisPropLayers(refLayer=Info.refLayer)`` for every row of ``params`` (``rows``: the local-info row of
-        each parameter vector, see ``set_local_info``)."""
+    def _grid_groups(self, params):
+        """The grid points of every row of ``params`` ([B, N + K], local constants appended), grouped by fine-layer signature:
+        yields (rows, (z, vs, vp, rho, qs, qp) float64 [n, G], group codes int [G]) - ``Model1D.seisPropGrids(refLayer)``
+        (models.py:72-91): interface points doubled, layers thinner than hLowerLimit skipped.  Also returns whether the
+        structure is static and the signatures (for the layer count of ``seis_prop_layers``)."""
         torch = self.torch
-        params = self._full(params, rows)
         B = params.shape[0]
         ref_layer = bool(self.info.get("refLayer", False))
         z_start = -self._topo.get(params).clamp(min=0.0)   # models.py:74, per row
@@ -452,15 +452,13 @@ class Model1DBatch:
             sig = torch.stack(sig, dim=1)                      # [B, nlayers]
             uniq, inv = torch.unique(sig, dim=0, return_inverse=True)
             uniq = uniq.cpu()
-        Lcap = int((uniq.clamp(min=0) + 1).sum(dim=1).max().item()) + (21 if ref_layer else 0)
-        out = [torch.zeros((B, Lcap), dtype=torch.float64, device=self.device) for _ in range(6)]
-        nlay = torch.zeros(B, dtype=torch.int32, device=self.device)
+        groups = []
         for g in range(uniq.shape[0]):
-            rows = slice(None) if static else (inv == g).nonzero(as_tuple=True)[0]     # (shadows the argument: consumed above)
+            rows = slice(None) if static else (inv == g).nonzero(as_tuple=True)[0]
             p = params[rows]
-            nrows = p.shape[0]
             zbot = z_start[rows].clone()
             cols = [[] for _ in range(6)]
+            codes = []
             crust_h = torch.zeros_like(zbot)
             for li, lay in enumerate(self.layers):
                 N = int(uniq[g, li].item())
@@ -469,6 +467,7 @@ class Model1DBatch:
                 z, vs, vp, rho, qs, qp = self._layer_grid(lay, p, zbot, N, crust_h)
                 for c_, a in zip(cols, (z + zbot[:, None], vs, vp, rho, qs, qp)):
                     c_.append(a)
+                codes += [self.GROUP_CODE[self.GROUP[lay["kind"]]]] * z.shape[1]
                 zbot = zbot + z[:, -1]
                 if self.GROUP[lay["kind"]] == "crust":
                     crust_h = crust_h + z[:, -1]
@@ -482,7 +481,46 @@ class Model1DBatch:
                 one = torch.ones_like(zr)
                 for c_, a in zip(cols, (zr + zbot[:, None], vs, vp, rho, qs0 * one, qp0 * one)):
                     c_.append(a)
-            z, vs, vp, rho, qs, qp = (torch.cat(c_, dim=1) for c_ in cols)
+                codes += [self.GROUP_CODE["mantle"]] * 21
+            groups.append((rows, tuple(torch.cat(c_, dim=1) for c_ in cols), codes))
+        return groups, static, uniq, ref_layer
+
+    GROUP_NAMES = ("water", "sediment", "crust", "mantle")
+    GROUP_CODE = {n: i for i, n in enumerate(GROUP_NAMES)}
+
+    def seis_prop_grids(self, params, rows=None):
+        """``Model1D.seisPropGrids(refLayer=Info.refLayer)`` (models.py:72-91) for every row of ``params``:
+        (z, vs, vp, rho, qs, qp) float64 [B, Gmax] padded with zeros - the grid points of every layer from the surface
+        down, interface points doubled as in the reference -, grp int64 [B, Gmax] (index into ``GROUP_NAMES``, -1 in the
+        padding) and ngrid[B]."""
+        torch = self.torch
+        params = self._full(params, rows)
+        B = params.shape[0]
+        groups, _, _, _ = self._grid_groups(params)
+        Gmax = max(g[1][0].shape[1] for g in groups)
+        out = [torch.zeros((B, Gmax), dtype=torch.float64, device=self.device) for _ in range(6)]
+        grp = torch.full((B, Gmax), -1, dtype=torch.int64, device=self.device)
+        ngrid = torch.zeros(B, dtype=torch.int32, device=self.device)
+        for rws, arrs, codes in groups:
+            n = arrs[0].shape[1]
+            for o, a in zip(out, arrs):
+                o[rws, :n] = a
+            grp[rws, :n] = torch.as_tensor(codes, dtype=torch.int64, device=self.device)[None, :]
+            ngrid[rws] = n
+        return tuple(out), grp, ngrid
+
+    def seis_prop_layers(self, params, rows=None):
+        """(h, vs, vp, rho, qs, qp) float64 [B, Lmax] padded with zeros, and nlay[B] -
+        ``Model1D.seisPropLayers(refLayer=Info.refLayer)`` for every row of ``params`` (``rows``: the local-info row of
+        each parameter vector, see ``set_local_info``)."""
+        torch = self.torch
+        params = self._full(params, rows)
+        B = params.shape[0]
+        groups, static, uniq, ref_layer = self._grid_groups(params)
+        Lcap = int((uniq.clamp(min=0) + 1).sum(dim=1).max().item()) + (21 if ref_layer else 0)
+        out = [torch.zeros((B, Lcap), dtype=torch.float64, device=self.device) for _ in range(6)]
+        nlay = torch.zeros(B, dtype=torch.int32, device=self.device)
+        for rws, (z, vs, vp, rho, qs, qp), _ in groups:
             h = z[:, 1:] - z[:, :-1]                       # models.py:95-101
             mids = [h] + [(a[:, 1:] + a[:, :-1]) / 2 for a in (vs, vp, rho, qs, qp)]
             keep = h > H_LOWER
@@ -492,8 +530,8 @@ class Model1DBatch:
             valid = torch.arange(L, device=self.device)[None, :] < n[:, None]
             for o, a in zip(out, mids):
                 a = torch.gather(a, 1, order) * valid
-                o[rows, :L] = a
-            nlay[rows] = n.to(torch.int32)
+                o[rws, :L] = a
+            nlay[rws] = n.to(torch.int32)
         # static structure: the interface duplicates are the only rows ever dropped, their number is
         # known, so the width is known without asking the device
         Lmax = (Lcap - 1 - (len([n for n in self._static_sig if n >= 0]) - 1 + (1 if ref_layer else 0))

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Golden vectors for ``Model1D.seisPropGrids`` (models.py:72-91) from the imported reference Python (development container
+only; see _refimport.py): depth / Vs / Vp / rho / Qs / Qp at the grid points of every layer - interface points doubled, as
+the reference returns them - and the group of each point, for parameter vectors drawn by the reference's own
+``MCinv.reset()``; a continental setting (with the reference mantle), an oceanic one and the per-point ('topo') case.
+
+    python tests/golden/make_golden_grids.py        ->  tests/golden/ref_grids.npz
+"""
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refimport  # noqa: E402
+
+_refimport.install()
+from pySurfInv.models import buildModel1D            # noqa: E402
+from settings import CONT, OCEAN                     # noqa: E402
+
+GROUPS = ["water", "sediment", "crust", "mantle"]
+
+
+def capture(setting, nsamp, seed, local=None):
+    random.seed(seed)
+    mod0 = buildModel1D(setting, local) if local is not None else buildModel1D(setting)
+    ref = setting['Info'].get('refLayer', False)
+    mods = [mod0] + [mod0.reset() for _ in range(nsamp - 1)]
+    P, Gd, NG = [], [], []
+    for m in mods:
+        P.append(m._brownians())
+        z, vs, vp, rho, qs, qp, grp = m.seisPropGrids(refLayer=ref)
+        Gd.append(np.array([z, vs, vp, rho, qs, qp, [GROUPS.index(g) for g in grp]], float)); NG.append(len(z))
+    arr = np.zeros((nsamp, 7, max(NG)))
+    for i, a in enumerate(Gd):
+        arr[i, :, :a.shape[1]] = a
+    return dict(params=np.array(P), grids=arr, ngrid=np.array(NG))
+
+
+def main():
+    out = {}
+    for name, setting in (("cont", CONT), ("ocean", OCEAN)):
+        d = capture(setting, 12, seed=21)
+        for k, v in d.items():
+            out[f"{name}/{k}"] = v
+        print(name, d["grids"].shape, np.unique(d["ngrid"]))
+    out["groups"] = np.array(GROUPS)
+    np.savez_compressed(os.path.join(HERE, "ref_grids.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -43,6 +43,32 @@ def test_layer_stacks_match_reference_seisPropLayers(name, setting):
     assert np.allclose(model[:, 3].numpy(), ref[:, 0], atol=1e-5)
 
 
+GG = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_grids.npz"))
+
+
+@pytest.mark.parametrize("name,setting", [("cont", CONT), ("ocean", OCEAN)])
+def test_grid_points_match_reference_seisPropGrids(name, setting):
+    """Model1D.seisPropGrids (models.py:72-91) - depth, Vs, Vp, rho, Qs, Qp at the grid points of every layer, interface
+    points doubled, and the group of each point - for 12 parameter vectors drawn by the reference's own reset()
+    (tests/golden/make_golden_grids.py): <= 1e-9, ragged point counts (the ocean models have 68..71) included."""
+    m = Model1DBatch(setting)
+    params = torch.from_numpy(GG[f"{name}/params"])
+    (z, vs, vp, rho, qs, qp), grp, ngrid = m.seis_prop_grids(params)
+    ref = GG[f"{name}/grids"]
+    assert np.array_equal(ngrid.numpy(), GG[f"{name}/ngrid"]) and len(np.unique(GG["ocean/ngrid"])) > 1
+    assert list(Model1DBatch.GROUP_NAMES) == list(GG["groups"])
+    for a, r in zip((z, vs, vp, rho, qs, qp), np.moveaxis(ref[:, :6], 1, 0)):
+        assert a.shape == r.shape and np.abs(a.numpy() - r).max() < 1e-9
+    for i, n in enumerate(GG[f"{name}/ngrid"]):
+        assert np.array_equal(grp[i, :n].numpy(), ref[i, 6, :n].astype(np.int64)) and bool((grp[i, n:] == -1).all())
+    # seisPropLayers is the midpoint form of these grids (models.py:93-102)
+    (h, vsl, *_), nlay = m.seis_prop_layers(params)
+    i = 0
+    zz, vv = z[i, :ngrid[i]].numpy(), vs[i, :ngrid[i]].numpy()
+    keep = np.diff(zz) > 0.01
+    assert np.allclose(h[i, :nlay[i]].numpy(), np.diff(zz)[keep]) and np.allclose(vsl[i, :nlay[i]].numpy(), ((vv[1:] + vv[:-1]) / 2)[keep])
+
+
 def test_param_spec_bounds_follow_BrownianVarMC():
     s = brownian.ParamSpec.from_entries([[2., 'abs_pos', 3., 0.1], [10., 'rel', 30, 9.], [1., 0.5, 1.6, 0.05],
                                          [4., 'rel_pos', 200, 0.4], [0., 'abs', 0.4, 0.01]])
