@@ -79,3 +79,84 @@ class Point:
 
     def copy(self):
         return copy.deepcopy(self)
+
+
+class _ModelState:
+    """What the post-processing keeps of a model: its random-walk parameters (``_brownians()`` order), misfit, likelihood."""
+
+    def __init__(self, params, misfit=None, L=None):
+        self.params = np.asarray(params, float)
+        self.misfit, self.L = misfit, L
+
+    def _brownians(self):
+        return list(self.params)
+
+
+class PostPoint(Point):
+    """Drop-in for the compute part of the reference's ``PostPoint`` (point.py:134-175, 307-335): reads one point's
+    ``{pid}.npz`` (keys ``mcTrack, setting, obs, invMeta`` - the reference's files and this package's alike) and derives
+
+    * ``MCparas`` with rejected rows replaced by the last accepted row before them (``trueMarkovChain``, :154-159);
+    * ``minMod`` = the row of the smallest misfit (:161-165), ``thres = max(2 min, min + 0.5)`` (:307-309),
+      ``accFinal = misfits < thres`` (:167-168);
+    * ``avgMod`` = mean parameters of the final rows (:170-171) with its misfit and likelihood from ONE forward solve on
+      the device (:173);
+    * ``_loadValues(indVars)`` = the final rows' parameters (:317-335, the parameter branch), ``_model_generator``.
+
+    ``minMod`` / ``avgMod`` carry ``params`` (``_brownians()`` order), ``misfit``, ``L``; ``initMod`` is the point's
+    ``Model1DBatch`` (``seis_prop_layers(params)`` / ``seis_prop_grids(params)`` give any of them as a profile).  The plotting
+    methods of the reference are out of scope.  ``device=None``: no forward solve (``avgMod.misfit`` stays None)."""
+
+    def __init__(self, npzMC=None, npzPriori=None, modelTypeCustom=None, layerClassCustom={}, trueMarkovChain=True,
+                 device="cuda:0", _forward=None):
+        self.MCparas_pri = None
+        self._forward = _forward
+        if npzMC is not None:
+            tmp = np.load(npzMC, allow_pickle=True)
+            self.MC, setting, obs = np.array(tmp["mcTrack"], float), tmp["setting"][()], tmp["obs"][()]
+            self.invMeta = tmp["invMeta"][()]
+            Point.__init__(self, setting, modelTypeCustom=modelTypeCustom, layerClassCustom=layerClassCustom,
+                           periods=obs["T"], vels=obs["c"], uncers=obs["uncer"], device=device if device is not None else "cpu")
+            self.pid = self.invMeta.get("pid", self.pid) if isinstance(self.invMeta, dict) else self.pid
+            self.N = self.MC.shape[0]
+            self.misfits, self.Ls, self.accepts = self.MC[:, 0], self.MC[:, 1], self.MC[:, 2]
+            self.MCparas = self.MC[:, 3:]
+            if trueMarkovChain and self.N:
+                idx = np.where(self.accepts.astype(bool), np.arange(self.N), -1)
+                last = np.maximum.accumulate(idx)
+                if last[0] < 0:                                       # the reference would fail here too (iAcc undefined)
+                    raise ValueError("mcTrack does not start with an accepted row")
+                self.MCparas = self.MCparas[last]
+                self.MC = np.concatenate([self.MC[:, :3], self.MCparas], axis=1)
+            ind_min = int(np.nanargmin(self.misfits))
+            self.minMod = _ModelState(self.MCparas[ind_min], float(self.misfits[ind_min]), float(self.Ls[ind_min]))
+            self.thres = self._thres(self.minMod.misfit)
+            self.accFinal = self.misfits < self.thres
+            self.avgMod = _ModelState(self.MCparas[self.accFinal].mean(axis=0))
+            if device is not None or _forward is not None:
+                self.avgMod.misfit, _, self.avgMod.L = self.misfit(self.avgMod.params)
+        if npzPriori is not None:
+            self.MCparas_pri = np.array(np.load(npzPriori, allow_pickle=True)["mcTrack"], float)[:, 3:]
+
+    def _sampler(self, seed=None, **kw):
+        if self._forward is not None:
+            kw.setdefault("forward", self._forward)
+        return Point._sampler(self, seed=seed, **kw)
+
+    @staticmethod
+    def _thres(minMisfit):
+        return max(minMisfit * 2, minMisfit + 0.5)
+
+    def _model_generator(self, indSteps=None, priori=False):
+        """Parameter vectors of the final rows (or of ``indSteps``; ``priori``: every row of the prior run)."""
+        paras = self.MCparas if not priori else self.MCparas_pri
+        if indSteps is None:
+            indSteps = np.where(self.accFinal)[0] if not priori else range(len(self.misfits))
+        for ind in indSteps:
+            yield _ModelState(paras[ind])
+
+    def _loadValues(self, indVars="all", priori=False):
+        """[n_vars, n_final] parameter values of the final rows (the reference's ``zdeps=None`` branch)."""
+        indVars = range(self.MCparas.shape[1]) if isinstance(indVars, str) and indVars == "all" else indVars
+        paras = self.MCparas[self.accFinal] if not priori else self.MCparas_pri[self.accFinal]
+        return np.array([mc[list(indVars)] for mc in paras]).T

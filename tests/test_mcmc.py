@@ -418,3 +418,48 @@ def test_chain_groups_do_not_change_the_chains():
     mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], G["trace/c_obs"], G["trace/uncer"], device=dev, seed=1)
     assert mc.chain_groups(MetropolisBatch.GROUP_MIN_CHAINS - 1) is None
     assert mc.chain_groups(MetropolisBatch.GROUP_MIN_CHAINS).G == 2
+
+
+# ------------------------------------------------------------------ PostPoint (point.py:134-175, 307-335)
+GP = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_post.npz"), allow_pickle=True)
+POST_NPZ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "post_trace.npz")
+
+
+def _check_post(p, key, tol_misfit):
+    assert np.array_equal(p.MCparas, GP[f"{key}/MCparas"])
+    assert np.array_equal(p.minMod.params, GP[f"{key}/min_params"]) and p.minMod.misfit == float(GP[f"{key}/min_misfit"])
+    assert p.minMod.L == float(GP[f"{key}/min_L"]) and p.thres == float(GP[f"{key}/thres"])
+    assert np.array_equal(p.accFinal, GP[f"{key}/accFinal"])
+    assert np.abs(p.avgMod.params - GP[f"{key}/avg_params"]).max() < 1e-12
+    assert np.array_equal(p._loadValues(), GP[f"{key}/values"]) and np.array_equal(p._loadValues(indVars=[0, 3, 7]), GP[f"{key}/values_sub"])
+    assert len(list(p._model_generator())) == int(GP[f"{key}/accFinal"].sum())
+    if tol_misfit is not None:
+        assert abs(p.avgMod.misfit / float(GP[f"{key}/avg_misfit"]) - 1) < tol_misfit
+        assert abs(p.avgMod.L / float(GP[f"{key}/avg_L"]) - 1) < 50 * tol_misfit
+
+
+@pytest.mark.parametrize("tmc,key", [(True, "tmc"), (False, "raw")])
+def test_postpoint_matches_reference_postpoint(tmc, key):
+    """The reference's PostPoint on the reference's own 240-row trace file (tests/golden/make_golden_post.py): parameters
+    after the true-Markov-chain substitution, minimum-misfit model, threshold, final mask, average model, _loadValues -
+    exactly; the average model's misfit through the CPU oracle as forward (the checker standing in for the device here)."""
+    from pysurfinv_amd.point import PostPoint
+    p = PostPoint(POST_NPZ, trueMarkovChain=tmc, device=None, _forward=oracle_forward(np.asarray(G["trace/periods"], np.float32)))
+    assert p.N == 240 and p.invMeta["chainL"] == 80 and list(p.obs["T"]) == list(G["trace/periods"])
+    _check_post(p, key, 1e-6)
+    q = PostPoint(POST_NPZ, trueMarkovChain=tmc, device=None)          # no device, no forward: everything but the one solve
+    assert q.avgMod.misfit is None and np.array_equal(q.accFinal, p.accFinal)
+
+
+@pytest.mark.gpu
+def test_postpoint_on_the_device_and_on_our_own_files(tmp_path):
+    from pysurfinv_amd.point import Point, PostPoint
+    p = PostPoint(POST_NPZ, device="cuda:0")
+    _check_post(p, "tmc", 1e-5)
+    # a file written by this package's Point.MCinvMP reads back the same way
+    pt = Point(CONT, periods=list(G["trace/periods"]), vels=list(G["trace/c_obs"]), uncers=list(G["trace/uncer"]), device="cuda:0")
+    arr = pt.MCinvMP(outdir=str(tmp_path), pid="here", runN=600, chainL=60, seed=3)
+    q = PostPoint(os.path.join(str(tmp_path), "here.npz"), device="cuda:0")
+    assert q.N == 600 and np.array_equal(q.misfits, arr[:, 0]) and q.pid == "here"
+    assert q.minMod.misfit == np.nanmin(arr[:, 0]) and q.accFinal.sum() >= 1 and np.isfinite(q.avgMod.misfit)
+    assert q.avgMod.misfit < q.thres * 1.5
