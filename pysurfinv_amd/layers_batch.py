@@ -428,14 +428,14 @@ class Model1DBatch:
         return torch.where(H < H_LOWER, torch.full_like(N, -1), N), H     # -1: layer skipped (models.py:80-81)
 
     # ------------------------------------------------------------------ public
-    def _grid_groups(self, params):
+    def _grid_groups(self, params, ref_layer=None):
         """The grid points of every row of ``params`` ([B, N + K], local constants appended), grouped by fine-layer signature:
         yields (rows, (z, vs, vp, rho, qs, qp) float64 [n, G], group codes int [G]) - ``Model1D.seisPropGrids(refLayer)``
         (models.py:72-91): interface points doubled, layers thinner than hLowerLimit skipped.  Also returns whether the
         structure is static and the signatures (for the layer count of ``seis_prop_layers``)."""
         torch = self.torch
         B = params.shape[0]
-        ref_layer = bool(self.info.get("refLayer", False))
+        ref_layer = bool(self.info.get("refLayer", False)) if ref_layer is None else bool(ref_layer)
         z_start = -self._topo.get(params).clamp(min=0.0)   # models.py:74, per row
         # pass 1: fine-layer counts (they depend on the thicknesses, hence on the parameters)
         static = self._static_sig is not None
@@ -488,15 +488,15 @@ class Model1DBatch:
     GROUP_NAMES = ("water", "sediment", "crust", "mantle")
     GROUP_CODE = {n: i for i, n in enumerate(GROUP_NAMES)}
 
-    def seis_prop_grids(self, params, rows=None):
-        """``Model1D.seisPropGrids(refLayer=Info.refLayer)`` (models.py:72-91) for every row of ``params``:
+    def seis_prop_grids(self, params, rows=None, ref_layer=None):
+        """``Model1D.seisPropGrids(refLayer)`` (models.py:72-91; ``ref_layer=None``: Info.refLayer) for every row of ``params``:
         (z, vs, vp, rho, qs, qp) float64 [B, Gmax] padded with zeros - the grid points of every layer from the surface
         down, interface points doubled as in the reference -, grp int64 [B, Gmax] (index into ``GROUP_NAMES``, -1 in the
         padding) and ngrid[B]."""
         torch = self.torch
         params = self._full(params, rows)
         B = params.shape[0]
-        groups, _, _, _ = self._grid_groups(params)
+        groups, _, _, _ = self._grid_groups(params, ref_layer)
         Gmax = max(g[1][0].shape[1] for g in groups)
         out = [torch.zeros((B, Gmax), dtype=torch.float64, device=self.device) for _ in range(6)]
         grp = torch.full((B, Gmax), -1, dtype=torch.int64, device=self.device)
@@ -508,6 +508,26 @@ class Model1DBatch:
             grp[rws, :n] = torch.as_tensor(codes, dtype=torch.int64, device=self.device)[None, :]
             ngrid[rws] = n
         return tuple(out), grp, ngrid
+
+    def value(self, params, zdeps, rows=None, type="vs"):
+        """``Model1D.value(zdeps)`` (models.py:104-108) for every row of ``params``: Vs at the depths ``zdeps``, linearly
+        interpolated on ``seisPropGrids()`` - WITHOUT the reference mantle, as the reference calls it -, NaN outside.
+        float64 numpy [B, len(zdeps)] (post-processing: numpy's own ``interp``, row by row, so that doubled interface
+        points resolve exactly as in the reference)."""
+        if type != "vs":
+            raise ValueError("Error: only support vs, others to be added...")       # models.py:105-106
+        (z, vs, *_), _, ngrid = self.seis_prop_grids(params, rows, ref_layer=False)
+        z, vs, ngrid = z.cpu().numpy(), vs.cpu().numpy(), ngrid.cpu().numpy()
+        zd = np.asarray(zdeps, float)
+        return np.stack([np.interp(zd, z[i, :n], vs[i, :n], left=np.nan, right=np.nan) for i, n in enumerate(ngrid)])
+
+    def moho(self, params, rows=None):
+        """``Model1D.moho()`` (models.py:110-112): depth of the first mantle grid point, float64 numpy [B]."""
+        (z, *_), grp, _ = self.seis_prop_grids(params, rows, ref_layer=False)
+        first = (grp == self.GROUP_CODE["mantle"]).to(self.torch.int8).argmax(dim=1)
+        if not bool((grp == self.GROUP_CODE["mantle"]).any(dim=1).all()):
+            raise ValueError("'mantle' is not in list")                              # what list.index raises in the reference
+        return z.gather(1, first[:, None]).squeeze(1).cpu().numpy()
 
     def seis_prop_layers(self, params, rows=None):
         """(h, vs, vp, rho, qs, qp) float64 [B, Lmax] padded with zeros, and nlay[B] -

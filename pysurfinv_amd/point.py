@@ -155,8 +155,14 @@ class PostPoint(Point):
         for ind in indSteps:
             yield _ModelState(paras[ind])
 
-    def _loadValues(self, indVars="all", priori=False):
-        """[n_vars, n_final] parameter values of the final rows (the reference's ``zdeps=None`` branch)."""
+    def _loadValues(self, indVars="all", zdeps=None, indSteps=None, priori=False):
+        """[n_vars, n_final] parameter values of the final rows; with ``zdeps``: [len(zdeps), n_rows] Vs at those depths of
+        the models of the final rows (or of ``indSteps``) - ``Model1D.value`` for all of them in one batched call where the
+        reference maps a process pool over them (point.py:317-335)."""
+        if zdeps is not None:
+            paras = np.array([m.params for m in self._model_generator(indSteps, priori=priori)])
+            import torch
+            return self.initMod.value(torch.as_tensor(paras, dtype=torch.float64, device=self.initMod.device), zdeps).T
         indVars = range(self.MCparas.shape[1]) if isinstance(indVars, str) and indVars == "all" else indVars
         paras = self.MCparas[self.accFinal] if not priori else self.MCparas_pri[self.accFinal]
         return np.array([mc[list(indVars)] for mc in paras]).T

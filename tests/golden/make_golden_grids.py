@@ -21,6 +21,7 @@ from pySurfInv.models import buildModel1D            # noqa: E402
 from settings import CONT, OCEAN                     # noqa: E402
 
 GROUPS = ["water", "sediment", "crust", "mantle"]
+ZDEPS = np.concatenate([np.linspace(-1.0, 60.0, 62), np.linspace(62.0, 260.0, 34)])
 
 
 def capture(setting, nsamp, seed, local=None):
@@ -28,15 +29,16 @@ def capture(setting, nsamp, seed, local=None):
     mod0 = buildModel1D(setting, local) if local is not None else buildModel1D(setting)
     ref = setting['Info'].get('refLayer', False)
     mods = [mod0] + [mod0.reset() for _ in range(nsamp - 1)]
-    P, Gd, NG = [], [], []
+    P, Gd, NG, V, M = [], [], [], [], []
     for m in mods:
         P.append(m._brownians())
         z, vs, vp, rho, qs, qp, grp = m.seisPropGrids(refLayer=ref)
         Gd.append(np.array([z, vs, vp, rho, qs, qp, [GROUPS.index(g) for g in grp]], float)); NG.append(len(z))
+        V.append(m.value(ZDEPS)); M.append(m.moho())       # models.py:104-112 (both on seisPropGrids() WITHOUT the reference mantle)
     arr = np.zeros((nsamp, 7, max(NG)))
     for i, a in enumerate(Gd):
         arr[i, :, :a.shape[1]] = a
-    return dict(params=np.array(P), grids=arr, ngrid=np.array(NG))
+    return dict(params=np.array(P), grids=arr, ngrid=np.array(NG), value=np.array(V), moho=np.array(M))
 
 
 def main():
@@ -47,6 +49,7 @@ def main():
             out[f"{name}/{k}"] = v
         print(name, d["grids"].shape, np.unique(d["ngrid"]))
     out["groups"] = np.array(GROUPS)
+    out["zdeps"] = ZDEPS
     np.savez_compressed(os.path.join(HERE, "ref_grids.npz"), **out)
 
 

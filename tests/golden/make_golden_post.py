@@ -21,6 +21,9 @@ from pySurfInv.point import PostPoint               # noqa: E402
 from settings import CONT                            # noqa: E402
 
 
+ZDEPS = np.linspace(0.5, 180.0, 37)
+
+
 def main():
     G = np.load(os.path.join(HERE, "ref_driver.npz"))
     obs = {"T": list(G["trace/periods"]), "c": list(G["trace/c_obs"]), "uncer": list(G["trace/uncer"])}
@@ -30,12 +33,15 @@ def main():
         p = PostPoint(f, trueMarkovChain=tmc)
         out = dict(MCparas=p.MCparas, min_params=np.array(p.minMod._brownians()), min_misfit=p.minMod.misfit, min_L=p.minMod.L,
                    thres=p.thres, accFinal=p.accFinal, avg_params=np.array(p.avgMod._brownians()), avg_misfit=p.avgMod.misfit,
-                   avg_L=p.avgMod.L, values=p._loadValues(), values_sub=p._loadValues(indVars=[0, 3, 7]))
+                   avg_L=p.avgMod.L, values=p._loadValues(), values_sub=p._loadValues(indVars=[0, 3, 7]),
+                   # _loadValues(zdeps=...) without its process pool: the expression the reference keeps beside it (point.py:327)
+                   values_z=np.array([mod.value(ZDEPS) for mod in p._model_generator()]).T)
         print("trueMarkovChain", tmc, "min misfit", p.minMod.misfit, "thres", p.thres, "final", int(p.accFinal.sum()), "avg misfit", p.avgMod.misfit)
         if tmc:
             res = {f"tmc/{k}": np.asarray(v) for k, v in out.items()}
         else:
             res.update({f"raw/{k}": np.asarray(v) for k, v in out.items()})
+    res["zdeps"] = ZDEPS
     np.savez_compressed(os.path.join(HERE, "ref_post.npz"), **res)
 
 

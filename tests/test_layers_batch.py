@@ -61,6 +61,13 @@ def test_grid_points_match_reference_seisPropGrids(name, setting):
         assert a.shape == r.shape and np.abs(a.numpy() - r).max() < 1e-9
     for i, n in enumerate(GG[f"{name}/ngrid"]):
         assert np.array_equal(grp[i, :n].numpy(), ref[i, 6, :n].astype(np.int64)) and bool((grp[i, n:] == -1).all())
+    # Model1D.value(zdeps) and moho() (models.py:104-112: on the grids WITHOUT the reference mantle, NaN outside)
+    val = m.value(params, GG["zdeps"])
+    assert val.shape == GG[f"{name}/value"].shape and np.array_equal(np.isnan(val), np.isnan(GG[f"{name}/value"]))
+    assert np.nanmax(np.abs(val - GG[f"{name}/value"])) < 1e-9 and np.isnan(val).any()
+    assert np.abs(m.moho(params) - GG[f"{name}/moho"]).max() < 1e-9
+    with pytest.raises(ValueError):
+        m.value(params, [1.0], type="vp")
     # seisPropLayers is the midpoint form of these grids (models.py:93-102)
     (h, vsl, *_), nlay = m.seis_prop_layers(params)
     i = 0

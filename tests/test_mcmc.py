@@ -433,6 +433,8 @@ def _check_post(p, key, tol_misfit):
     assert np.abs(p.avgMod.params - GP[f"{key}/avg_params"]).max() < 1e-12
     assert np.array_equal(p._loadValues(), GP[f"{key}/values"]) and np.array_equal(p._loadValues(indVars=[0, 3, 7]), GP[f"{key}/values_sub"])
     assert len(list(p._model_generator())) == int(GP[f"{key}/accFinal"].sum())
+    vz = p._loadValues(zdeps=GP["zdeps"])                               # Vs at depth of every final model (Model1D.value)
+    assert vz.shape == GP[f"{key}/values_z"].shape and np.nanmax(np.abs(vz - GP[f"{key}/values_z"])) < 1e-9
     if tol_misfit is not None:
         assert abs(p.avgMod.misfit / float(GP[f"{key}/avg_misfit"]) - 1) < tol_misfit
         assert abs(p.avgMod.L / float(GP[f"{key}/avg_L"]) - 1) < 50 * tol_misfit
