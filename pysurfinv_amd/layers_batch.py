@@ -119,14 +119,24 @@ class _Slot:
 class Model1DBatch:
     LAYER_TYPES = {"Sediment": "sed", "Crust": "crust", "Mantle": "mantle", "OceanMantle": "mantle",
                    "OceanWater": "water", "OceanSediment": "osed", "OceanCrust": "ocrust",
-                   "OceanSedimentCascadia": "osedc", "OceanMantleHybrid": "hybrid"}
+                   "OceanSedimentCascadia": "osedc", "OceanMantleHybrid": "hybrid",
+                   # the LayerName keys Model1D.toYML() writes (models.py:60-70) - what the reference stores as `setting` in
+                   # its {pid}.npz files; its own layerClassDict does not know the two land names (layers.py:553-570)
+                   "LandSediment": "sed", "LandCrust": "crust"}
+    LAYER_NAME = {"sed": "LandSediment", "crust": "LandCrust", "mantle": "OceanMantle", "water": "OceanWater",
+                  "osed": "OceanSediment", "ocrust": "OceanCrust", "osedc": "OceanSedimentCascadia",
+                  "hybrid": "OceanMantleHybrid"}              # prop['LayerName'] of the reference's layer classes
     GROUP = {"sed": "sediment", "osed": "sediment", "osedc": "sediment", "crust": "crust", "ocrust": "crust",
              "mantle": "mantle", "hybrid": "mantle", "water": "water"}
 
-    def __init__(self, setting: dict, device="cpu", local_keys=None):
+    def __init__(self, setting, device="cpu", local_keys=None):
         import torch
         self.torch = torch
         self.device = torch.device(device)
+        if not isinstance(setting, dict):                  # a YAML file, as buildModel1D accepts (models.py:689-694)
+            import yaml
+            with open(setting, "r") as f:
+                setting = yaml.load(f, Loader=yaml.FullLoader)
         self.setting = setting
         self.info = dict(setting.get("Info", {}))
         entries, names = [], []
@@ -218,6 +228,38 @@ class Model1DBatch:
             sl.idx = self.spec.n + sl.aux
         self._basis = {}
         self._static_sig = self._find_static_signature()
+
+    def to_yml(self, params=None):
+        """``Model1D.toYML()`` (models.py:60-70) of the model with the random-walk values ``params`` (default: the
+        setting's own): {LayerName: parm with every random-walk entry as [v, vmin, vmax, step]} + ``Info`` - the form the
+        reference stores as ``setting`` in its ``{pid}.npz`` files; ``Model1DBatch`` reads it back (the LayerName keys
+        included)."""
+        import copy
+        v = np.asarray(self.spec.v0 if params is None else params, float).ravel()
+        if v.size != self.spec.n:
+            raise ValueError(f"{v.size} values for {self.spec.n} random-walk parameters")
+        it = iter(range(self.spec.n))
+
+        def conv(e):
+            if _is_brownian_entry(e):
+                i = next(it)
+                return [float(v[i]), float(self.spec.vmin[i]), float(self.spec.vmax[i]), float(self.spec.step[i])]
+            if _is_fixed_entry(e):
+                return e[0]                                # buildSeisLayer turns 'fixed' / 'total' entries into plain values
+            if isinstance(e, (list, tuple)):
+                return [conv(x) for x in e]
+            if isinstance(e, dict):
+                return {kk: conv(x) for kk, x in e.items()}
+            return copy.deepcopy(e)
+
+        out = {}
+        for lay, (key, parm) in zip(self.layers, ((kk, p) for kk, p in self.setting.items() if kk != "Info")):
+            out[self.LAYER_NAME[lay["kind"]]] = {kk: conv(x) for kk, x in parm.items()}
+            if lay["kind"] == "water":
+                out[self.LAYER_NAME["water"]]["Vs"] = 0    # OceanWater.__init__ sets parm['Vs'] = 0 (layers.py:195)
+        assert next(it, None) is None
+        out["Info"] = copy.deepcopy(self.info)
+        return out
 
     # ------------------------------------------------------------------ per-point local information
     @property

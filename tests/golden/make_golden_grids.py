@@ -38,7 +38,9 @@ def capture(setting, nsamp, seed, local=None):
     arr = np.zeros((nsamp, 7, max(NG)))
     for i, a in enumerate(Gd):
         arr[i, :, :a.shape[1]] = a
-    return dict(params=np.array(P), grids=arr, ngrid=np.array(NG), value=np.array(V), moho=np.array(M))
+    import json
+    yml = json.dumps([mods[0].toYML(), mods[3].toYML()])       # Model1D.toYML (models.py:60-70): what Point.MCinv stores as `setting`
+    return dict(params=np.array(P), grids=arr, ngrid=np.array(NG), value=np.array(V), moho=np.array(M), toyml=np.array(yml))
 
 
 def main():

@@ -76,6 +76,39 @@ def test_grid_points_match_reference_seisPropGrids(name, setting):
     assert np.allclose(h[i, :nlay[i]].numpy(), np.diff(zz)[keep]) and np.allclose(vsl[i, :nlay[i]].numpy(), ((vv[1:] + vv[:-1]) / 2)[keep])
 
 
+def _same(a, b, tol=1e-12):
+    if isinstance(a, dict):
+        return isinstance(b, dict) and list(a) == list(b) and all(_same(a[k], b[k], tol) for k in a)
+    if isinstance(a, (list, tuple)):
+        return isinstance(b, (list, tuple)) and len(a) == len(b) and all(_same(x, y, tol) for x, y in zip(a, b))
+    if isinstance(a, (int, float)) and not isinstance(a, bool) and isinstance(b, (int, float)):
+        return abs(a - b) <= tol * max(1.0, abs(b))
+    return a == b
+
+
+@pytest.mark.parametrize("name,setting", [("cont", CONT), ("ocean", OCEAN)])
+def test_to_yml_is_the_references_toYML_and_reads_back(name, setting, tmp_path):
+    """Model1D.toYML() (models.py:60-70) - the `setting` the reference stores in its {pid}.npz files: LayerName keys, every
+    random-walk entry as [v, vmin, vmax, step] - for the initial model and for a prior draw; Model1DBatch reads that form
+    back (also from a YAML file, as buildModel1D does) and builds the same model."""
+    import json
+    import yaml
+    m = Model1DBatch(setting)
+    ref0, ref3 = json.loads(str(GG[f"{name}/toyml"]))
+    assert _same(m.to_yml(), ref0), (m.to_yml(), ref0)
+    assert _same(m.to_yml(GG[f"{name}/params"][3]), ref3)
+    f = tmp_path / "setting.yml"
+    f.write_text(yaml.safe_dump(ref3, sort_keys=False))
+    for src in (ref3, str(f)):
+        m3 = Model1DBatch(src)
+        assert np.allclose(m3.spec.v0, GG[f"{name}/params"][3], atol=1e-12)
+        assert np.allclose(m3.spec.vmin, m.spec.vmin) and np.allclose(m3.spec.vmax, m.spec.vmax) and np.allclose(m3.spec.step, m.spec.step)
+        p = torch.from_numpy(GG[f"{name}/params"][:5])
+        (h1, v1, *_), n1 = m.seis_prop_layers(p)
+        (h3, v3, *_), n3 = m3.seis_prop_layers(p)
+        assert torch.equal(n1, n3) and torch.equal(h1, h3) and torch.equal(v1, v3)
+
+
 def test_param_spec_bounds_follow_BrownianVarMC():
     s = brownian.ParamSpec.from_entries([[2., 'abs_pos', 3., 0.1], [10., 'rel', 30, 9.], [1., 0.5, 1.6, 0.05],
                                          [4., 'rel_pos', 200, 0.4], [0., 'abs', 0.4, 0.01]])
