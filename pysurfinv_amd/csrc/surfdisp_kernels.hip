@@ -7,7 +7,7 @@
 // formula or a semantic rule is taken from it.
 //
 // Pipeline for one (batch, wave type):
-//   K0 surfdisp_prep_kernel   : AoS model[B][5][L] -> SoA mdl[9][L][B]; per-layer earth-flattening
+//   K0 surfdisp_prep_kernel   : AoS model[B][5][L] -> SoA mdl[9][L][B] and / or rows[B][9][L]; per-layer earth-flattening
 //                               factors computed ONCE per stack (flat1.f:33-69 recomputes them
 //                               40x per solve), validation.
 //   K1 surfdisp_phase_kernel  : phase velocities.  A TEAM of G lanes (G = 1..64, one wavefront holds
@@ -22,7 +22,10 @@
 //                               scan, SURFDISP_FASTSCAN), EXACT (the fallback instantiation that restates
 //                               DLTAR4 / DLTAR1 / NEVILL statement by statement for the stacks the
 //                               production arithmetic cannot treat faithfully); phase-only calls skip
-//                               the ellipticity recursions.
+//                               the ellipticity recursions.  The teams of a wavefront run in LOCK STEP: all
+//                               scan, then all refine, then all end their period (ST_WREF / ST_WEND).
+//   K1b surfdisp_ellip_kernel : Rayleigh ellipticities of teams of >= 4 lanes, one lane per (stack, period),
+//                               replaying the working stack's history the root search recorded.
 //   K2 surfdisp_group_kernel  : group velocities, one lane per (stack, period): eigenfunction
 //                               integration + energy integrals (surfa.f:714-1192 / 374-606), fp64 state
 //                               for Rayleigh as in the reference (surfa.f:717-722); the KERN
