@@ -498,8 +498,8 @@ def workload_mcmc(rt, args, steps=None, warmup=None):
                                   "96-layer continental model, 19 periods, Rayleigh phase-only misfit", "chains": 100}}
     mc = MetropolisBatch(mb.spec, mb.to_model, MCMC_PERIODS, c_obs[0], unc[0], device=rt.dev, seed=3 + rt.rank)
     from pysurfinv_amd import _lib, forward
-    # the sampler as the library runs it for 100 chains: speculative lock steps (MetropolisBatch.auto_spec_depth = 3: the
-    # tree of the next three accept / reject outcomes, 7 proposals per chain, ONE batched solve of 700 stacks, three
+    # the sampler as the library runs it for 100 chains: speculative lock steps (MetropolisBatch.auto_spec_depth = 4: the
+    # tree of the next four accept / reject outcomes, 15 proposals per chain, ONE batched solve of 1 500 stacks, four
     # Metropolis steps; the chain is distributed as the plain sampler's) - and, beside it, one step per solve
     d = mc.auto_spec_depth(100)
     M = (1 << d) - 1
@@ -516,6 +516,8 @@ def workload_mcmc(rt, args, steps=None, warmup=None):
                 "kernel_ms": {"prep": kms[0], "phase": kms[1], "finish": kms[2]},
                 "roofline": leg_roofline("mcmc", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * 100 * M,
                                          team=int(_lib.lib().surfdisp_get_team2(100 * M, L, len(MCMC_PERIODS), _lib.KIND_RAYLEIGH | _lib.PHASE_ONLY)))})
+    if os.environ.get("BENCH_MCMC_ONLY_DEFAULT") == "1":   # counter passes: one launch size per kernel instantiation
+        return out
     mc.run(100, 4, spec_depth=1); rt.barrier()
     t0 = time.perf_counter(); mc.run(100, K + 1, spec_depth=1); rt.barrier()
     dt1, = rt.max_over_ranks(time.perf_counter() - t0)

@@ -43,7 +43,7 @@ def run_grid(model_batch, lons, lats, periods, c_obs, uncer, chains_per_point, c
     c_obs, uncer: [n_points, P] (NaN / non-positive uncertainty = masked period)
     chain_groups: None (the sampler's default: two groups of chains on two streams from 4 096 chains per rank on,
                   ``MetropolisBatch.chain_groups``) or their number; the random numbers of every chain do not depend on it
-    spec_depth  : None (the sampler's default: speculative lock steps of depth 3 / 2 for up to 292 / 682 chains per rank,
+    spec_depth  : None (the sampler's default: speculative lock steps of depth 4 / 3 / 2 for up to 136 / 292 / 682 chains per rank,
                   ``MetropolisBatch.auto_spec_depth``) or the depth (1 = one step per forward solve)
     Returns dict(points=(lo, hi), mcTrack=[n_local, chains*chainL, 3+N] or None, summaries=[n_points, 6+2N+P]
     (every rank holds all rows, point order), columns, elapsed (sampling + summaries + gather, this rank),

@@ -272,15 +272,15 @@ class MetropolisBatch:
     SPEC_MAX_STACKS = 2048          # stacks per speculative lock step: a 64-lane team = one wavefront each, the chip holds 4 096
 
     def auto_spec_depth(self, C):
-        """Depth of the speculative lock step the fused path takes by default: the deepest tree (<= 3) whose
+        """Depth of the speculative lock step the fused path takes by default: the deepest tree (<= 4) whose
         C * (2^d - 1) stacks stay within ``SPEC_MAX_STACKS`` - a lock step of so few stacks is one wavefront per stack walking
         its periods one after the other on a mostly idle chip, and costs the same 0.9-1.0 ms for 100 stacks as for 700
         (100 chains x 96 layers: 0.96 ms per step plain, 0.345 with d = 3, 0.31 with d = 4 at 4.1 forward solves per step;
-        scripts/time_speculative.py); 1 from 683 chains on, and 1 where the (stack, period) decomposition fills the chip
+        scripts/time_speculative.py): 4 up to 136 chains, 3 up to 292, 2 up to 682, 1 from 683 chains on, and 1 where the (stack, period) decomposition fills the chip
         instead (``independent``: 0.24 ms per step plain, 0.29 with d = 3)."""
         if self.independent is True or (self.independent == "auto" and C < self.AUTO_INDEP_CHAINS):
             return 1
-        for d in (3, 2):
+        for d in (4, 3, 2):
             if C * ((1 << d) - 1) <= self.SPEC_MAX_STACKS:
                 return d
         return 1
@@ -401,7 +401,7 @@ class MetropolisBatch:
         Every proposal is still drawn from q(current state, .) and tested against the current state,
         so the chain is distributed exactly as with d = 1; only the order in which random numbers are
         consumed differs (the exact-replay path of the reference trace uses d = 1).  Default (None): on the fused device
-        path ``auto_spec_depth`` (3 for up to 292 chains, 2 up to 682, else 1), on the torch path 1.
+        path ``auto_spec_depth`` (4 for up to 136 chains, 3 up to 292, 2 up to 682, else 1), on the torch path 1.
 
         ``fused`` (default: whenever ``fused_available()``): the lock step as device kernels around the solver
         (``fused_step``: Philox random numbers keyed by the proposer's seed; same proposal and accept distributions).

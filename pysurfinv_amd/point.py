@@ -59,8 +59,8 @@ class Point:
         (point.py:91-125); writes ``{outdir}/{pid}.npz`` and returns the mcTrack array [runN, 3 + N].
         ``independent="auto"``: the period-parallel root search while the chains are too few to fill the chip (3 x faster
         lock steps for 100 chains; see ``MetropolisBatch``) - opt-in, the default is the reference's period walk.
-        ``spec_depth``: None = the sampler's default (speculative lock steps on the device path: three Metropolis steps per
-        batched solve for up to 292 chains, same chain distribution; ``MetropolisBatch.auto_spec_depth``), 1 = one step per solve."""
+        ``spec_depth``: None = the sampler's default (speculative lock steps on the device path: four Metropolis steps per
+        batched solve for up to 136 chains, three up to 292, same chain distribution; ``MetropolisBatch.auto_spec_depth``), 1 = one step per solve."""
         if priori and outdir.split("_")[-1] != "priori":
             outdir = "_".join((outdir, "priori"))
         pid = self.pid if pid is None else pid

@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 case $LEG in
   grid) STEPS="--steps 6 --warmup 2" ;;
   c5)   STEPS="--steps 8 --warmup 1" ;;
-  mcmc) STEPS="--steps 30 --warmup 2"; export BENCH_MCMC_NO_GRAPH=1 ;;   # (a --pmc pass hung on the HIP-graph replay of this leg)
+  mcmc) STEPS="--steps 30 --warmup 2"; export BENCH_MCMC_NO_GRAPH=1 BENCH_MCMC_ONLY_DEFAULT=1 ;;   # (a --pmc pass hung on the HIP-graph replay of this leg; only the default sampler: one launch size per kernel)
   *)    STEPS="--steps 5 --warmup 1 --no-cpu-baseline"; export BENCH_IN_FLIGHT=1 ;;
 esac
 BENCH="python3 $ROOT/bench.py --workload $LEG $STEPS $*"

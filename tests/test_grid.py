@@ -98,9 +98,9 @@ def test_grid_single_rank_gpu(tmp_path):
     r = grid.run_grid(Model1DBatch(CONT, device="cuda:0"), np.arange(NPTS), np.arange(NPTS), G["trace/periods"],
                       c, u, 8, 20, outdir=str(tmp_path), device="cuda:0", seed=2)
     assert r["mcTrack"].shape == (NPTS, 160, 16) and len(os.listdir(tmp_path)) == NPTS
-    # 40 chains: speculative lock steps of depth 3 by default - the first row, then 19 steps as 7 solves of 7 proposals per
+    # 40 chains: speculative lock steps of depth 4 by default - the first row, then 19 steps as 5 solves of 15 proposals per
     # chain; + one solve per point for the average model
-    assert r["report"]["forward_solves"] == NPTS * 8 * (1 + 7 * 7) + NPTS
+    assert r["report"]["forward_solves"] == NPTS * 8 * (1 + 15 * 5) + NPTS
     assert r["summaries"].shape == (NPTS, 6 + 26 + len(G["trace/periods"])) and np.isfinite(r["summaries"]).all()
     mis = r["mcTrack"][:, :, 0]
     assert (mis[mis < 88888] > 0).all() and np.isfinite(r["mcTrack"]).all()

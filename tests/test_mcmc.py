@@ -365,7 +365,7 @@ def test_fused_speculative_lock_steps(depth):
     mc = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], c_obs, unc, device=dev, seed=4)
     tr = mc.run(C, chainL, spec_depth=depth)
     d = depth or 3
-    assert mc.auto_spec_depth(C) == 3 and mc.auto_spec_depth(293) == 2 and mc.auto_spec_depth(683) == 1
+    assert mc.auto_spec_depth(100) == 4 and mc.auto_spec_depth(137) == 3 and mc.auto_spec_depth(C) == 3 and mc.auto_spec_depth(293) == 2 and mc.auto_spec_depth(683) == 1
     assert mc.n_forward == C * (1 + ((1 << d) - 1) * -(-(chainL - 1) // d))
     _check_chains(tr, mb, mc)
     mc1 = MetropolisBatch(mb.spec, mb.to_model, G["trace/periods"], c_obs, unc, device=dev, seed=4)
