@@ -50,6 +50,24 @@ def main():
         for k, v in d.items():
             out[f"{name}/{k}"] = v
         print(name, d["grids"].shape, np.unique(d["ngrid"]))
+    # PureGird (models.py:163-186): a model frozen as grid profiles - the continental start model with its reference mantle
+    # (doubled points at every interface) and a copy WITHOUT the doubled points (the pieces then close up at the boundaries)
+    from pySurfInv.models import PureGird
+    prof = buildModel1D(CONT).seisPropGrids(refLayer=True)
+    z = np.asarray(prof[0]); keep = np.concatenate([[True], np.diff(z) > 0])
+    for tag, pr in (("pg", prof), ("pg_nodup", tuple(np.asarray(a)[keep] for a in prof[:6]) + ([g for g, kk in zip(prof[6], keep) if kk],))):
+        pg = PureGird(pr, info={})
+        g = pg.seisPropGrids()
+        L = pg.seisPropLayers()
+        out[f"{tag}/in"] = np.array([np.asarray(a, float) for a in pr[:6]])
+        out[f"{tag}/in_grp"] = np.array([GROUPS.index(x) for x in pr[6]])
+        out[f"{tag}/grids"] = np.array([np.asarray(a, float) for a in g[:6]])
+        out[f"{tag}/grids_grp"] = np.array([GROUPS.index(x) for x in g[6]])
+        out[f"{tag}/layers"] = np.array([np.asarray(a, float) for a in L[:6]])
+        out[f"{tag}/value"] = pg.value(ZDEPS)
+        out[f"{tag}/moho"] = pg.moho()
+        out[f"{tag}/c"] = np.asarray(pg.forward([8, 12, 20, 30, 45, 60, 80]))
+        print(tag, out[f"{tag}/grids"].shape, out[f"{tag}/layers"].shape, out[f"{tag}/c"])
     out["groups"] = np.array(GROUPS)
     out["zdeps"] = ZDEPS
     np.savez_compressed(os.path.join(HERE, "ref_grids.npz"), **out)

@@ -171,3 +171,32 @@ def test_unknown_random_walk_keys_raise_and_crust_ignores_deg():
     import torch
     p = torch.as_tensor(np.asarray(mb.spec.v0)[None, :])
     assert torch.equal(ma.to_model(p)[0], mb.to_model(p)[0])
+
+
+@pytest.mark.parametrize("tag", ["pg", "pg_nodup"])
+def test_puregird_matches_reference(tag):
+    """PureGird (models.py:163-186): a model frozen as grid profiles, cut into one piece per group; seisPropGrids /
+    seisPropLayers / value / moho exactly as the reference's (fixtures: the continental start model with its reference
+    mantle, with and without doubled interface points - without them the pieces close up at the group boundaries)."""
+    from pysurfinv_amd.puregird import PureGird
+    names = list(GG["groups"])
+    prof = tuple(GG[f"{tag}/in"]) + ([names[i] for i in GG[f"{tag}/in_grp"]],)
+    pg = PureGird(prof, info={})
+    g = pg.seisPropGrids()
+    assert np.array_equal(np.array(g[:6]), GG[f"{tag}/grids"]) and [names.index(x) for x in g[6]] == list(GG[f"{tag}/grids_grp"])
+    L = pg.seisPropLayers()
+    assert np.array_equal(np.array(L[:6]), GG[f"{tag}/layers"]) and len(L[6]) == GG[f"{tag}/layers"].shape[1]
+    v = pg.value(GG["zdeps"])
+    assert np.array_equal(np.isnan(v), np.isnan(GG[f"{tag}/value"])) and np.nanmax(np.abs(v - GG[f"{tag}/value"])) == 0
+    assert pg.moho() == float(GG[f"{tag}/moho"])
+    assert len(pg.layers) == 3 and pg.copy().moho() == pg.moho()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["pg", "pg_nodup"])
+def test_puregird_forward_on_the_device(tag):
+    from pysurfinv_amd.puregird import PureGird
+    names = list(GG["groups"])
+    pg = PureGird(tuple(GG[f"{tag}/in"]) + ([names[i] for i in GG[f"{tag}/in_grp"]],), info={})
+    c = pg.forward([8, 12, 20, 30, 45, 60, 80])
+    assert c is not None and np.abs(np.asarray(c) / GG[f"{tag}/c"] - 1).max() < 1e-4      # the reference's own forward (flang build)
