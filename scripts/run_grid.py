@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--fast-scan", action="store_true", help="opt into the heuristic scan (SURFDISP_FASTSCAN)")
     ap.add_argument("--local-keys", default="", help="comma-separated per-point constants (topo, lithoAge, period, <Layer>.<key>): "
                                                      "columns of local_info[n, K] in --input")
+    ap.add_argument("--chain-groups", type=int, default=None, help="chain groups per rank (default: 2 from 4 096 chains on)")
+    ap.add_argument("--spec-depth", type=int, default=None, help="Metropolis steps per batched solve (default: 4 / 3 / 2 for up to "
+                                                                 "136 / 292 / 682 chains per rank, else 1)")
     args = ap.parse_args()
 
     import torch
@@ -75,7 +78,7 @@ def main():
         lons, lats = 230.0 + 0.5 * (np.arange(n) % 64), 40.0 + 0.5 * (np.arange(n) // 64)
     r = grid.run_grid(mb, lons, lats, periods, c_obs, uncer, args.chains, args.chainL, outdir=args.outdir,
                       rank=rank, world=world, device=str(dev), seed=args.seed, fast_scan=args.fast_scan, keep_tracks=False,
-                      local_info=local_info)
+                      local_info=local_info, chain_groups=args.chain_groups, spec_depth=args.spec_depth)
     if rank == 0:
         os.makedirs(args.outdir, exist_ok=True)
         np.savez_compressed(os.path.join(args.outdir, "summaries.npz"), summaries=r["summaries"], columns=np.array(r["columns"]),
