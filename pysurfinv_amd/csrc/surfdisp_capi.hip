@@ -30,6 +30,7 @@ struct EnvKnobs {
     int device = 0;               // SURFDISP_DEVICE (fast_surf_)
     int balance = -1;             // SURFDISP_BALANCE (developer knob): wavefront priority by progress, -1 = automatic
     int lockstep = -1;            // SURFDISP_LOCKSTEP (developer knob): -1 = automatic (on), 0 / 1, 2 = also for (stack, period) units
+    int certscan = 1;             // SURFDISP_CERTSCAN (developer knob): 0 = Love root searches walk every grid point (no certified skipping)
     int host_slots = 3;           // SURFDISP_HOST_SLOTS (developer knob): chunks in flight of a large host-buffer call (2 or 3)
     long host_chunk_layers = 327680;   // SURFDISP_HOST_CHUNK (developer knob): layers' worth of stacks per chunk
     int host_pipeline = 1;        // SURFDISP_HOST_PIPELINE (developer knob): 0 = large host-buffer calls as one chunk
@@ -55,6 +56,7 @@ struct EnvKnobs {
         if (const char *e = getenv("SURFDISP_ROWS_MIN_TEAM")) rows_min_team = atoi(e);
         if (const char *e = getenv("SURFDISP_LOCKSTEP")) lockstep = atoi(e);
         if (const char *e = getenv("SURFDISP_HOST_PIPELINE")) host_pipeline = atoi(e);
+        if (const char *e = getenv("SURFDISP_CERTSCAN")) certscan = atoi(e);
         if (const char *e = getenv("SURFDISP_HOST_SLOTS")) host_slots = atoi(e);
         if (const char *e = getenv("SURFDISP_HOST_CHUNK")) { host_chunk_layers = atol(e); if (host_chunk_layers < 1024) host_chunk_layers = 1024; }
     }
@@ -285,8 +287,12 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     // heuristic one; SURFDISP_EXACTSCAN (ABI 1) is accepted and wins over both
     const EnvKnobs &kn = knobs();
     const bool strict = (kind & SURFDISP_STRICT) != 0;
-    const bool fastscan = ((kind & SURFDISP_FASTSCAN) != 0 || kn.fastscan) && (kind & SURFDISP_EXACTSCAN) == 0 && !strict;
+    const bool exactscan = (kind & SURFDISP_EXACTSCAN) != 0;
+    bool fastscan = ((kind & SURFDISP_FASTSCAN) != 0 || kn.fastscan) && !exactscan && !strict;
     kind &= ~SD_KIND_FLAGS;
+    // Love: the coarse scan with its Sturm-count certificate (phase_body, CERT) is the DEFAULT - it returns the bracket the
+    // point-by-point scan returns, by a theorem, not a heuristic; SURFDISP_EXACTSCAN / SURFDISP_CERTSCAN=0 walk every point
+    if (kind == SURFDISP_KIND_LOVE) fastscan = !exactscan && !strict && (kn.certscan != 0 || fastscan);
     // the ellipticity recursions (two more evaluations per period) feed the group-velocity kernel - and the caller who
     // asked for the ratio itself (ABI 3), also in a phase-only call
     const bool want_ell = (kind == SURFDISP_KIND_RAYLEIGH) && (!phase_only || ratio != nullptr);

@@ -643,9 +643,17 @@ __device__ __noinline__ float delta_rayleigh_ref(const float *wq, const int LS, 
 // from zero: c == b then runs through the oscillatory formulas with rb = 1e-15, which give the reference's degenerate
 // values y = -k d, z = 0, cosq = 1 of surfa.f:163-165 to 1e-15); 1/(rho b^2) comes from the working stack (the slot the
 // Rayleigh recursion keeps its density ratios in).  Three transcendentals per evanescent layer instead of five.
+// CERT: also the Sturm count of the trial - kc = net number of times the (displacement, stress) vector has crossed
+// "stress = 0" clockwise on the way up from the half space (see the certified scan in phase_body), kunc = the count is not
+// safe (a sign or a multiple of pi within rounding).  In a layer where c > b the pair (ut, tt / (h rb)) ROTATES by
+// q = -k d rb: floor(|q| / pi) or one more crossings, the parity being whether tt changed sign; where c < b it moves along
+// a hyperbola towards the diagonal and can cross at most once, counter-clockwise.
+template <bool CERT = false>
 __device__ __forceinline__ float delta_love(const float *wq, const int LS, const int S,
-                                            const int mmax, const float c, const float T, float &phi)
+                                            const int mmax, const float c, const float T, float &phi, int &kc, bool &kunc,
+                                            const bool count = true)
 {
+    kc = 0; kunc = !count;                                 // (count = false: no certificate from this trial)
     phi = 0.0f;                                            // see delta_rayleigh
     const float wvno = 6.2831853f * rcp_nr(c * T);
     const float csq = c * c;
@@ -680,6 +688,23 @@ __device__ __forceinline__ float delta_love(const float *wq, const int LS, const
         phi -= (arg < 0.0f) ? 0.0f : q;
         const float eut = cosq * ut - yv * tt * ih;
         const float ett = h * z * ut + cosq * tt;
+        if (CERT && count) {
+            const bool flip = (tt < 0.0f) != (ett < 0.0f);
+            if (arg < 0.0f) {
+                kc -= flip ? 1 : 0;
+                // a pair that enters an evanescent layer close to its DECAYING direction (a mode trapped in a low-velocity
+                // channel below a lid) leaves it as the difference of two e^{|q|} terms: below 1e-3 of them the sign of the
+                // stress - here and in the point-by-point scan's secular function next to this trial - is rounding noise
+                kunc = kunc || !(fabsf(ett) > 1.0e-3f * (fabsf(h * z * ut) + fabsf(cosq * tt)));
+            } else {
+                const float t = -q * 0.318309886f;         // |q| / pi
+                const float nf = floorf(t), r = t - nf;
+                const int nfull = (int)nf;
+                kc += nfull + (((nfull & 1) != 0) != flip ? 1 : 0);
+                kunc = kunc || (r > 1.0f - 4.0e-4f) || (nfull >= 1 && r < 4.0e-4f);      // |q| within ~1e-3 rad of a multiple of pi
+            }
+            kunc = kunc || !(fabsf(ett) > 1.0e-5f * (fabsf(ett) + fabsf(h * rb * eut)));  // stress ~ 0 at an interface (or not finite)
+        }
         ut = eut; tt = ett;
     };
     int m = mh - 1;
@@ -854,6 +879,20 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     // judged free of sign changes (see below), otherwise its fine points are scanned as usual
     constexpr int FSTRIDE = 4;
     constexpr bool fastok = FAST && (G >= 2) && (G <= 8);
+    // CERT (Love): the coarse scan's certificate is a THEOREM instead of the heuristics below.  At fixed frequency the angle of
+    // the pair (displacement, stress) at the surface, followed continuously up from the half space, falls monotonically as
+    // the trial velocity rises (Sturm / Pruefer), and a mode sits wherever it passes a multiple of pi: the number of modes
+    // between two trial velocities is the difference of their crossing counts (delta_love<true>; checked against brute-force
+    // root counts on 120 000 random pairs).  Two coarse points with EQUAL counts, the same effective half space (layer
+    // dropping is monotone in c) and both below the half-space velocity have no root - hence no sign change at any grid
+    // point - between them: the points in between need not be evaluated, and the bracket the point-by-point scan finds is
+    // the one this scan finds.  An unsafe count (a sign or a multiple of pi within rounding) fails the certificate.
+    // Teams of up to 8 lanes (stacks of up to ~30 layers): 65 536 x L10 0.71 -> 0.52 ms, 65 536 x L30 1.61 -> 1.17 ms; with 16
+    // lanes (deep stacks) one plain pass already covers 16 grid points and the coarse pass's dearer evaluations ate the
+    // gain (16 384 x L64: 1.12 -> 1.21 ms), so they keep the plain scan.  Checked against the point-by-point scan bit for
+    // bit on 3.1e8 random stacks (scripts/soak_cert.py).
+    constexpr bool CERT = fastok && (KIND == 1) && !EXACT;
+    int p0Kp = 0x40000000;             // Sturm count at p0 (CERT), packed: count + 4096, bit 30 = unsafe
     // ... and only on stacks where two modes cannot sit within one coarse interval: velocities that never
     // decrease with depth (no channel waves) and no layer thicker than three wavelengths of the period at
     // hand (overtones of a thick layer crowd together as (c T / 2h)^2)
@@ -956,6 +995,8 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         first = true;
         defer = (!EXACT && A.strict != 0) || entry_overflow_risk(p0c);    // SURFDISP_STRICT: everything to the exact kernel
         nodrop = no_drop_possible(p0c);
+        // CERT: a period in which no trial can drop layers (one eigenproblem for every trial velocity) starts on the coarse grid
+        if (CERT) coarse = nodrop;
     }
 
     int wprio = -1;
@@ -994,7 +1035,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             cj = ell_c; mmj = ell_mm; start = 2 + j; wl = wq2; Tl = ell_T;
         } else if (st == ST_SCAN) {
             // exact fp32 grid of the reference: c2 = c1 + dc repeatedly (calcul.f:157,161)
-            const int nadd = (fastok && coarse) ? FSTRIDE * (js + 1) : (first ? js : js + 1);
+            const int nadd = (fastok && coarse) ? FSTRIDE * (first ? js : js + 1) : (first ? js : js + 1);   // (CERT may start a period on the coarse grid)
             cj = p0c;
             if (fastok) {
 #pragma unroll
@@ -1033,6 +1074,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             eval = (G == 1) || (j < 2);
         }
         float val = 0.0f, phj = 0.0f;
+        int kcj = 0; bool kuncj = false;                       // Sturm count of this lane's trial (CERT)
 #ifdef SD_WAVECLOCK
         const unsigned long long we0 = __builtin_readcyclecounter();
         wcyc_pre += we0 - wp0;                                 // priority, trial velocities, layer dropping
@@ -1050,7 +1092,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         if (eval) {
             if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, LS, S, mmj, cj, Tl, start)
                                        : delta_rayleigh<(G != 2) && !FAST>(wl, LS, S, mmj, cj, Tl, start, phj);
-            else           val = EXACT ? delta_love_ref(wl, LS, S, mmj, cj, Tl) : delta_love(wl, LS, S, mmj, cj, Tl, phj);
+            else           val = EXACT ? delta_love_ref(wl, LS, S, mmj, cj, Tl) : delta_love<CERT>(wl, LS, S, mmj, cj, Tl, phj, kcj, kuncj, coarse);   // counts only where they are compared: coarse passes
         }
 #ifdef SD_WAVECLOCK
         wcyc_eval += __builtin_readcyclecounter() - we0;
@@ -1062,6 +1104,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         const float pd = (j == 0) ? p0d : sv_;
         const int smm = __shfl(mmj, lm1);
         const int pmm = (j == 0) ? p0mm : smm;
+        const int kpk = CERT ? ((kcj + 4096) | (kuncj ? 0x40000000 : 0)) : 0;          // count | unsafe flag, packed
+        const int sKp = CERT ? __shfl(kpk, lm1) : 0;                                   // ... of the previous lane
+        const int pKp = (j == 0) ? p0Kp : sKp;
         const bool searching = ((st == ST_SCAN) || (st == ST_REFINE)) && !ell_lane;
         const bool has_prev = !((st == ST_SCAN) && first && (js == 0));
         auto negnan = [](float x) { return signbit(x) && !(x != x); };   // a NaN compares as positive, see below
@@ -1074,7 +1119,16 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         // half space at the coarse points around it, and ln|Delta| bends so little at BOTH ends of the
         // interval that no pair of roots can hide in it.  Anything else is rescanned point by point.
         bool uncert = false, back0 = false;
-        if (fastok) {
+        if (CERT) {
+            if (coarse && st == ST_SCAN) {
+                // below the half-space velocity by two coarse steps (there the problem stops being an eigenvalue problem)
+                const bool near_hs = !(cj < W_B(mmj - 1) - 2.0f * (float)FSTRIDE * DC);
+                // ... and the scan's lower guard (calcul.f:165: a trial below 0.8 b(1) ends the search) looks at every grid
+                // point: the first one a skip would pass over is pc + dc
+                const bool low_guard = (pc + DC) < 0.8f * b1top;
+                uncert = has_prev && (near_hs || low_guard || !((pmm == mmj) && fin(pd) && fin(val) && !kuncj && (pKp == kpk)));
+            }
+        } else if (fastok) {
         const int ln1 = (lane + 1) & 63, lm2 = (lane + 62) & 63;
         const float nx_d = __shfl(val, ln1), sp_d = __shfl(val, lm2);
         const int nx_mm = __shfl(mmj, ln1), sp_mm = __shfl(mmj, lm2);
@@ -1141,6 +1195,8 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         const int lastl = tbase + G - 1;
         const float l_c = __shfl(cj, lastl), l_d = __shfl(val, lastl);
         const float l_phi = fastok ? __shfl(phj, lastl) : 0.0f;
+        const int l_Kp = CERT ? __shfl(kpk, lastl) : 0;
+        const int e_pKp = CERT ? __shfl(pKp, src) : 0;
         // the values of the team's first two lanes: the two ellipticity recursions, and NEVILL's del3 (every lane of the team
         // evaluated the same c3) - only where some team of the wavefront needs them
         float v0 = 0.0f, v1 = 0.0f;
@@ -1198,14 +1254,17 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             ++passes;
             if (fl >= 0) {                                     // rescan this interval point by point
                 p0c = e_pc; p0d = e_pd; p0mm = e_pmm;
+                if (CERT) p0Kp = e_pKp;
                 const bool e_back = (fl == tbase) && (t_back0 != 0);
                 if (e_back) { p0c = q0c; p0d = q0d; p0mm = q0mm; }
                 // after a failed certificate stay on the fine grid for the next interval too (a restart at q0
                 // has two intervals to cover; a change of the layer dropping usually sits close to the root)
                 coarse = false; fine_left = (e_cross && !e_back) ? FSTRIDE : 2 * FSTRIDE; q0ok = false;
+                if (CERT) { fine_left = FSTRIDE; first = false; }      // (the certified scan rescans the one interval)
             } else {
                 q0c = pl_c; q0d = pl_d; q0mm = pl_mm; q0ok = true;
                 p0c = l_c; p0d = l_d; p0mm = l_mm; p0phi = l_phi;
+                if (CERT) { p0Kp = l_Kp; first = false; }
             }
         } else if (st == ST_SCAN) {
             ++passes;
@@ -1226,11 +1285,14 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 failed = true;                                 // label 250
             } else {
                 p0c = l_c; p0d = l_d; p0mm = l_mm; first = false;
+                if (CERT) p0Kp = l_Kp;
                 if (fastok) { p0phi = l_phi; q0d = pl_d; q0mm = pl_mm; }    // pl: the fine point p0 - dc
                 if (passes > 100000) failed = true;            // cannot happen: c grows by dc/pass
                 if (fastok) {
                     fine_left -= had_ell ? G - 2 : G;
-                    if (fine_left <= 0 && fsafe <= 3.0f * p0c * T) { coarse = true; q0ok = false; }
+                    if (fine_left <= 0 && (CERT ? nodrop : (fsafe <= 3.0f * p0c * T))) { coarse = true; q0ok = false; }
+                    // (CERT: fine passes carry no counts, so the coarse pass starts AT p0 - its first lane evaluates it again)
+                    if (CERT && coarse) first = true;
                 }
             }
         } else if (!EXACT && st == ST_REFINE && multi) {
@@ -1432,6 +1494,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 st = ST_SCAN;
                 defer = entry_overflow_risk(p0c);              // acted on at the end of the next pass
                 nodrop = no_drop_possible(p0c);
+                if (CERT) coarse = nodrop;
             }
         }
 #ifdef SD_WAVECLOCK

@@ -276,6 +276,34 @@ def test_large_host_buffer_calls_are_chunked_and_pipelined(hip, B, L, kind):
     assert np.array_equal(c2, c)
 
 
+@pytest.mark.parametrize("B,L,team,rough", [(20000, 10, 0, False), (20000, 10, 4, True), (4096, 64, 8, False), (4096, 30, 8, True),
+                                             (3000, 21, 2, True), (30000, 30, 0, True)])
+def test_love_certified_scan_is_the_point_by_point_scan(hip, B, L, team, rough):
+    """Love root searches skip grid points between two coarse points whose Sturm counts agree (a theorem,
+    not a heuristic).  Every result - c, U, status, zeros - equals the point-by-point scan's (SURFDISP_EXACTSCAN) BIT FOR
+    BIT: same brackets, hence the same refinement; smooth and rough (unsorted, sigma 0.15) stacks, water on top of some,
+    ragged layer counts, every team size the certified scan is instantiated for and the library's own choice."""
+    import torch
+    from pysurfinv_amd import _lib, synth, forward
+    per = synth.default_periods(23)
+    kw = {} if L == 10 else {"total_thickness": 220.0}
+    model = synth.synth_models(B, L, seed=31, **(dict(kw, noise=0.15, monotone=False) if rough else kw))
+    if L >= 6:
+        model[::9, 1, 0] = 0.0; model[::9, 0, 0] = 1.475; model[::9, 2, 0] = 1.027; model[::9, 4, 0] = 1e-4      # a water layer on top
+    nlay = np.full(B, L, np.int32); nlay[::7] = max(2, L - 2)
+    dm, dp, dn = torch.from_numpy(model).cuda(), torch.from_numpy(per).cuda(), torch.from_numpy(nlay).cuda()
+    _lib.lib().surfdisp_set_team(team)
+    try:
+        plan = forward.BatchPlan(B, L, len(per))
+        c1, u1, s1 = (t.clone() for t in plan.run(dm, dp, kind=1, nlay=dn))
+        c0, u0, s0 = (t.clone() for t in plan.run(dm, dp, kind=1 | _lib.EXACTSCAN, nlay=dn))
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().surfdisp_set_team(0)
+    assert torch.equal(c1, c0) and torch.equal(s1, s0) and torch.equal(u1.nan_to_num(-7.0), u0.nan_to_num(-7.0))
+    assert float((c1 > 0).float().mean()) > 0.9
+
+
 def test_extreme_velocities_follow_the_reference(hip):
     """Stacks far outside seismology.  Vs x 3 (roots up to ~14 km/s) must agree with the oracle.  Vs x 6 puts the
     roots above 16 km/s, where one fp32 ulp (1.9e-6) exceeds NEVILL's 1e-6 bracket tolerance: the REFERENCE never
