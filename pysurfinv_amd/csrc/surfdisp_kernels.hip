@@ -41,6 +41,9 @@
 #include "surfdisp_internal.h"
 
 #define SD_HD __host__ __device__
+#ifndef SD_CERT_STRIDE
+#define SD_CERT_STRIDE 6       // grid points per lane of a certified coarse pass, teams of <= 4 lanes (4: 0.516 ms, 6: 0.483, 8: 0.491 for 65 536 x L10)
+#endif
 
 namespace sd {
 
@@ -877,7 +880,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     // opt-in fast scan (teams of 2..8 lanes): after the first pass of a period the scan advances
     // FSTRIDE grid points per lane; an interval between two coarse points is skipped only if it is
     // judged free of sign changes (see below), otherwise its fine points are scanned as usual
-    constexpr int FSTRIDE = 4;
+    constexpr int FSTRIDE = (FAST && KIND == 1 && G <= 4) ? SD_CERT_STRIDE : 4;
     constexpr bool fastok = FAST && (G >= 2) && (G <= 8);
     // CERT (Love): the coarse scan's certificate is a THEOREM instead of the heuristics below.  At fixed frequency the angle of
     // the pair (displacement, stress) at the surface, followed continuously up from the half space, falls monotonically as
