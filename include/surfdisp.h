@@ -49,7 +49,10 @@ extern "C" {
                                      * second batch of this size in flight on another stream, so the lanes per
                                      * stack are chosen for twice the stacks (fewer lanes per stack waste fewer
                                      * trial velocities; with one batch alone they would leave SIMDs idle) */
-#define SURFDISP_EXACTSCAN     0x80 /* accepted and ignored (ABI 1 spelling): the point-by-point scan is the default */
+#define SURFDISP_EXACTSCAN     0x80 /* OR into `kind`: every grid point of the scan is evaluated.  Rayleigh: that is the default
+                                     * anyway (the flag wins over SURFDISP_FASTSCAN).  Love: the default skips grid points
+                                     * between two coarse points that a counting theorem proves free of roots (same brackets
+                                     * and results, bit for bit); this flag walks them all (what the A/B tests compare with). */
 #define SURFDISP_FASTSCAN      0x100 /* OR into `kind`: OPT-IN heuristic scan.  By default the secular function is
                                      * evaluated at EVERY 0.01 km/s grid point from 0.9 c(k-1) up to the first sign
                                      * change, as the reference does (calcul.f:143-166).  With this flag teams of

@@ -18,7 +18,7 @@ KIND_LOVE, KIND_RAYLEIGH = 1, 2
 PHASE_ONLY = 0x10
 INDEPENDENT = 0x20
 PIPELINED = 0x40
-EXACTSCAN = 0x80        # ABI 1 spelling, accepted and ignored: the point-by-point scan is the default
+EXACTSCAN = 0x80        # every grid point of the scan (Rayleigh: the default anyway; Love: switches the certified coarse scan off)
 FASTSCAN = 0x100        # opt-in heuristic scan (include/surfdisp.h)
 STRICT = 0x200          # verification mode: every stack through the statement-by-statement kernel
 NPER_MAX, NLAY_MAX = 200, 200

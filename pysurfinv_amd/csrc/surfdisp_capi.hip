@@ -140,7 +140,10 @@ int pick_team(int B, int Lmax, bool need_ratio = true, bool pipelined = false, i
     // the caller sizes a Love launch for its own stacks even beside another stream's kernels (forward_device_impl: 16 384 x L64
     // beside the Rayleigh root search of a joint solve, teams of 16 instead of 8: 6.59 -> 6.24 ms); measured with the four-field
     // Love working stack, scripts/sweep_team.py, profiles/r03a/love_team.txt, profiles/r03b/sweep_team_lockstep.txt
-    if (kind == SURFDISP_KIND_LOVE && !g_team_override.load(std::memory_order_relaxed) && !knobs().team && !knobs().team_love && G < 4)
+    // (with the certified coarse scan of teams of <= 8 lanes two-lane teams win again on very large batches - 131 072 x L10:
+    // 0.73 ms against 0.81 with four lanes - so the floor only holds where that scan is switched off)
+    if (kind == SURFDISP_KIND_LOVE && !g_team_override.load(std::memory_order_relaxed) && !knobs().team && !knobs().team_love && G < 4 &&
+        knobs().certscan == 0)
         G = 4;
     if (G < 1) G = 1;
     if (G > 64) G = 64;

@@ -35,7 +35,7 @@ def test_workspace_and_team_heuristics():
     assert L.surfdisp_get_team(1, 10) == 64              # one stack: a whole wavefront
     assert L.surfdisp_get_team(1 << 20, 10) == 4         # huge batch, alone on the chip: four lanes per stack ...
     assert L.surfdisp_get_team2(1 << 20, 10, 20, _lib.KIND_RAYLEIGH | _lib.PIPELINED) == 2     # ... two beside another batch in flight
-    assert L.surfdisp_get_team2(1 << 20, 10, 20, _lib.KIND_LOVE) == 4                          # Love: never fewer than four
+    assert L.surfdisp_get_team2(1 << 20, 10, 20, _lib.KIND_LOVE) == 2                          # Love (certified coarse scan): two again
     assert L.surfdisp_get_team(65536, 10) == 4           # the bench workload
     g = L.surfdisp_get_team(1 << 20, 200)                # LDS bound forces wider teams
     assert g >= 8 and 4 * 200 * (256 // g) * 4 <= 80 * 1024
