@@ -890,10 +890,10 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     // dropping is monotone in c) and both below the half-space velocity have no root - hence no sign change at any grid
     // point - between them: the points in between need not be evaluated, and the bracket the point-by-point scan finds is
     // the one this scan finds.  An unsafe count (a sign or a multiple of pi within rounding) fails the certificate.
-    // Teams of up to 8 lanes (stacks of up to ~30 layers): 65 536 x L10 0.71 -> 0.52 ms, 65 536 x L30 1.61 -> 1.17 ms; with 16
+    // Teams of up to 8 lanes (stacks of up to ~30 layers): 65 536 x L10 0.71 -> 0.48 ms, 65 536 x L30 1.61 -> 1.05 ms; with 16
     // lanes (deep stacks) one plain pass already covers 16 grid points and the coarse pass's dearer evaluations ate the
     // gain (16 384 x L64: 1.12 -> 1.21 ms), so they keep the plain scan.  Checked against the point-by-point scan bit for
-    // bit on 3.1e8 random stacks (scripts/soak_cert.py).
+    // bit on 5.7e8 random stacks (scripts/soak_cert.py).
     constexpr bool CERT = fastok && (KIND == 1) && !EXACT;
     int p0Kp = 0x40000000;             // Sturm count at p0 (CERT), packed: count + 4096, bit 30 = unsafe
     // ... and only on stacks where two modes cannot sit within one coarse interval: velocities that never
