@@ -45,6 +45,10 @@ def lib():
         L.surfdisp_oracle_forward_at.restype = ctypes.c_int
         L.surfdisp_oracle_forward_at.argtypes = [ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, fp,
                                                  ctypes.c_int, fp, fp, fp]
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.surfdisp_oracle_partials.restype = ctypes.c_int
+        L.surfdisp_oracle_partials.argtypes = [ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, ctypes.c_float,
+                                               dp, dp, dp, dp, ip, ip, fp, fp]
         _lib = L
     return _lib
 
@@ -99,6 +103,37 @@ def forward_batch(model, periods, kind, nlay=None, nthreads=1):
                                         status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
                                         int(nthreads))
     return c, u, status
+
+
+def partials(vp, vs, rho, h, qsinv, period, kind):
+    """The analytic partials of one period as the reference's REIGEN / LEIGEN leave them in COMMON /rar1/
+    (oracle/refso.py::last_partials is the same read-out of the reference itself): dict(dcda, dcdb, dcdr, dwx
+    float64[1000], mmax, ndiv, c, u, status)."""
+    vp, vs, rho, h, qsinv = map(_f32, (vp, vs, rho, h, qsinv))
+    out = [np.zeros(1000, np.float64) for _ in range(4)]
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    mm = ctypes.c_int(0); nd = ctypes.c_int(0); c = ctypes.c_float(0); u = ctypes.c_float(0)
+    st = lib().surfdisp_oracle_partials(vp.size, int(kind), _fp(vp), _fp(vs), _fp(rho), _fp(h), _fp(qsinv),
+                                        float(period), dp(out[0]), dp(out[1]), dp(out[2]), dp(out[3]),
+                                        ctypes.byref(mm), ctypes.byref(nd), ctypes.byref(c), ctypes.byref(u))
+    return dict(dcda=out[0], dcdb=out[1], dcdr=out[2], dwx=out[3], mmax=mm.value, ndiv=nd.value,
+                c=c.value, u=u.value, status=st)
+
+
+def sum_sublayers(arr, nlay, ndiv, mmax, water):
+    """Per-sublayer entries of COMMON /rar1/ -> per INPUT layer (sum over a layer's ndiv sublayers, surfa.f:789-820:
+    layers jj..n-1 are split, jj = 2 with a water top, the half space is the last entry; the block is shifted one
+    entry down when the top is solid).  Entries at or beyond ``mmax`` (layers dropped by that call) are zero."""
+    a = np.asarray(arr, np.float64)
+    sh = 0 if water else 1                       # entry of sublayer 1 (0-based index)
+    out = np.zeros(nlay)
+    jj = 2 if (water and ndiv > 1) else 1
+    pos = sh
+    for lay in range(1, nlay + 1):               # 1-based input layer
+        nsub = 1 if (lay < jj or lay == nlay or ndiv <= 1) else ndiv
+        out[lay - 1] = a[pos:pos + nsub].sum()
+        pos += nsub
+    return out
 
 
 def group_at(model, periods, kind, c_at, nlay=None):

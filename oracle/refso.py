@@ -61,6 +61,25 @@ def last_ratio(nper):
     return np.array([o[base + k] for k in range(int(nper))], np.float32)
 
 
+def last_partials(nsub=None):
+    """COMMON /rar1/ dcda, dcdb, dcdr, dwx (real*8[1000] each; surfa.f:390,396 / 722,729) and COMMON /rar/ mmax as the
+    LAST REIGEN / LEIGEN call left them: the analytic partial derivatives of the phase velocity with respect to the
+    P velocity, S velocity and density of every SUBLAYER of the flattened, attenuation-corrected stack that call
+    worked on (surfa.f:1133-1135, 1182-1184, 1204-1207; Love 511-512, 564-565, 582-583), shifted one entry down
+    when the top layer is solid (entry 1 = the surface, zero: surfa.f:1211-1249 / 608-631).  CALCUL calls the
+    routine once per period, so make ONE-period calls to read a given period's values.  Returns a dict with the
+    four arrays (first ``nsub`` entries, default all 1000), ``mmax`` (COMMON /rar/, after the shift) and ``ndiv``
+    (COMMON /c/, as clamped by the call: surfa.f:783-784 / 414-415)."""
+    L = lib()
+    blk = (ctypes.c_double * 4000).in_dll(L, "rar1_")
+    a = np.frombuffer(blk, dtype=np.float64).copy().reshape(4, 1000)
+    # COMMON /rar/ dept1(1000), ampur(1000), ampuz(1000), stresz(1000), stresr(1000), mmax
+    rar = (ctypes.c_int32 * 5001).in_dll(L, "rar_")
+    c_blk = (ctypes.c_int32 * 9).in_dll(L, "c_")
+    n = 1000 if nsub is None else int(nsub)
+    return dict(dcda=a[0, :n], dcdb=a[1, :n], dcdr=a[2, :n], dwx=a[3, :n], mmax=int(rar[5000]), ndiv=int(c_blk[5]))
+
+
 def fast_surf(nlay, ilvry, vp, vs, rho, h, qsinv, per, nper, fresh=True):
     """Reference fast_surf(): returns (ur0, ul0, cr0, cl0), float32[200] each."""
     L = lib()

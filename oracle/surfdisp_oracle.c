@@ -45,6 +45,10 @@ typedef struct {
     /* REIGEN knot storage yy1..4, yz1..4 (surfa.f:737-738), fp64; [sublayer][knot] */
     double yy1[NKN][5], yy2[NKN][5], yy3[NKN][5], yy4[NKN][5];
     double yz1[NKN][5], yz2[NKN][5], yz3[NKN][5], yz4[NKN][5];
+    /* COMMON /rar1/ dcda, dcdb, dcdr, dwx (surfa.f:722,729 / 390,396: DOUBLE PRECISION) and COMMON /rar/ mmax as the
+     * last REIGEN / LEIGEN call left them: the analytic partials per SUBLAYER of the flattened, attenuated stack */
+    double dcda[NSZ], dcdb[NSZ], dcdr[NSZ], dwx[NSZ];
+    int rar_mmax;
     /* counters for the work model (not in the reference) */
     long n_delta;
     /* developer trace of the scan of one period (surfdisp_oracle_scan_trace; not in the reference) */
@@ -432,7 +436,9 @@ static float leigen(ctx_t *s, float t, float c)
     float wvnosq = wvno * wvno;
     float tmp = 6.2831853f / t;
     float omegsq = tmp * tmp;
-    (void)wvnosq; (void)omegsq;
+    const float xxmin = 1.0e-20f;                        /* surfa.f:404 */
+    float amp[NSZ];                                      /* displacement at the middle knot of each sublayer, surfa.f:553 */
+    for (int j = 0; j < NSZ; ++j) { amp[j] = 0.0f; s->dcdr[j] = 0.0; s->dcdb[j] = 0.0; }   /* surfa.f:461-466 */
     float ut0 = 1.0f;
     float ut, tq, sumi0, sumi1;
 restart:
@@ -442,10 +448,14 @@ restart:
         float h = rho[mmax - 1] * b[mmax - 1] * b[mmax - 1];
         float rb = wvno * sqrtf(fabsf(covb * covb - 1.0f));
         tq = -h * rb * ut0;
+        amp[mmax - 1] = ut;                              /* surfa.f:497 */
         float dm, sm;
         if (rb == 0.0f) { dm = 1.0e25f; sm = 0.0f; }
         else { dm = 0.5f / rb; sm = 0.5f * rb; }
-        (void)sm;
+        float dldr = omegsq * dm;                        /* surfa.f:509-512 (REAL*4 expressions stored to REAL*8) */
+        float dldm = -(wvnosq * dm + sm);
+        s->dcdb[mmax - 1] = 2.0f * rho[mmax - 1] * b[mmax - 1] * c * dldm / wvno;
+        s->dcdr[mmax - 1] = (c / wvno) * (dldr + b[mmax - 1] * b[mmax - 1] * dldm);
         sumi0 = rho[mmax - 1] * dm;
         sumi1 = h * dm;
     }
@@ -457,8 +467,9 @@ restart:
         float rb = wvno * sqrtf(fabsf(covb * covb - 1.0f));
         float h = rho[m - 1] * b[m - 1] * b[m - 1];
         float dz = d[m - 1] / 4.0f;
-        float dmm[5];
+        float dmm[5], smm[5];
         dmm[0] = ut * ut;
+        smm[0] = (tq / h) * (tq / h);                    /* surfa.f:530: (tq/h)**2 */
         float eut = ut, ett = tq;
         for (int kk = 2; kk <= 5; ++kk) {
             float xkk = (float)(kk - 1);
@@ -478,12 +489,40 @@ restart:
             eut = cosq * ut - y * tq / h;
             ett = -h * z * ut + cosq * tq;
             dmm[kk - 1] = eut * eut;
+            smm[kk - 1] = (ett * ett) / (h * h);         /* surfa.f:552 */
+            if (kk == 3) amp[m - 1] = eut;               /* surfa.f:553-554 */
         }
         ut = eut; tq = ett;
         float dm = (dz / 22.5f) * (7.0f * (dmm[0] + dmm[4]) + 32.0f * (dmm[1] + dmm[3]) + 12.0f * dmm[2]);
+        float sm = (dz / 22.5f) * (7.0f * (smm[0] + smm[4]) + 32.0f * (smm[1] + smm[3]) + 12.0f * smm[2]);
+        float dldm = -(wvnosq * dm + sm);                /* surfa.f:562-565 */
+        float dldr = omegsq * dm;
+        s->dcdb[m - 1] = 2.0f * rho[m - 1] * b[m - 1] * c * dldm / wvno;
+        s->dcdr[m - 1] = (c / wvno) * (dldr + b[m - 1] * b[m - 1] * dldm);
         sumi0 = sumi0 + rho[m - 1] * dm;
         sumi1 = sumi1 + h * dm;
     }
+    {   /* surfa.f:573-597: scale by dL/dk; "exclusion of low amplitudes" */
+        s->dcdb[NSZ - 1] = 0.0; s->dcdr[NSZ - 1] = 0.0;
+        float dldk = -2.0f * wvno * sumi1;
+        for (int l = 1; l <= mmax; ++l) {
+            if (b[l - 1] == 0.0f) continue;
+            amp[l - 1] = amp[l - 1] / ut;
+            s->dcdb[l - 1] = s->dcdb[l - 1] / dldk;
+            s->dcdr[l - 1] = s->dcdr[l - 1] / dldk;
+            if (!(b[l - 1] < b[mmax - 1]) && (fabsf(amp[l - 1]) - xxmin < 0.0f)) { s->dcdb[l - 1] = 0.0; s->dcdr[l - 1] = 0.0; }
+        }
+    }
+    s->rar_mmax = mmax;
+    if (!(b[0] <= 0.0f)) {                               /* surfa.f:609-631: one entry down, entry 1 = the surface */
+        for (int l = 1; l <= mmax; ++l) {
+            int i = mmax - l + 1, j = i + 1;
+            s->dcdb[j - 1] = s->dcdb[i - 1];
+            s->dcdr[j - 1] = s->dcdr[i - 1];
+        }
+        s->rar_mmax = mmax + 1;
+    }
+    s->dcdb[0] = 0.0; s->dcdr[0] = 0.0;
     sumi0 = sumi0 / (ut * ut);
     sumi1 = sumi1 / (ut * ut);
     return sumi1 / (c * sumi0);                          /* surfa.f:606 */
@@ -543,6 +582,7 @@ static float reigen(ctx_t *s, float t, float c, float ratio)
         xmu[i] = rho[i] * b[i] * b[i];
         xlamb[i] = rho[i] * (a[i] * a[i] - 2.0f * b[i] * b[i]);
     }
+    for (int j = 0; j < nmax; ++j) { s->dcda[j] = 0.0; s->dcdb[j] = 0.0; s->dcdr[j] = 0.0; }   /* surfa.f:839-842 */
     /* layer dropping, surfa.f:853-866 */
     float dmax = s->fact * t * c;
     {
@@ -748,6 +788,14 @@ static float reigen(ctx_t *s, float t, float c, float ratio)
         sumi1 = (float)((xlamb[i0] + 2.0f * xmu[i0]) * dmmr + xmu[i0] * dmmz + sumi1);
         sumi2 = (float)(xmu[i0] * dzsr - xlamb[i0] * drsz + sumi2);
         sumi3 = (float)((xlamb[i0] + 2.0f * xmu[i0]) * smmz + xmu[i0] * smmr + sumi3);
+        {   /* surfa.f:1130-1135 (dldl, dldm, dldr DOUBLE PRECISION; the REAL*4 factors are formed first, left to right) */
+            double dldl = -wvnosq * dmmr + 2.0f * wvno * drsz - smmz;
+            double dldm = -wvnosq * (2.0 * dmmr + dmmz) - 2.0f * wvno * dzsr - (2.0 * smmz + smmr);
+            double dldr = omegsq * (dmmr + dmmz);
+            s->dcdb[i0] = 2.0f * rho[i0] * b[i0] * c * (dldm - 2.0 * dldl) / wvno;
+            s->dcda[i0] = 2.0f * rho[i0] * a[i0] * c * dldl / wvno;
+            s->dcdr[i0] = (c / wvno) * (dldr + xlamb[i0] * dldl / rho[i0] + xmu[i0] * dldm / rho[i0]);
+        }
         if (fabsf(auz) + fabsf(aur) - xxmin <= 0.0f) goto halfspace;   /* -> 7002 */
     }
     if (m > mmax) m = mmax + 1; /* DO exhausted (cannot happen: m==mmax breaks) */
@@ -765,16 +813,51 @@ halfspace:
         float a2 = -wvno * rb * bp / rho[i0];
         float a3 = ra * ap / rho[i0];
         float a4 = wvnosq * bp / rho[i0];
-        if (rb == 0.0f) return b[i0];                    /* label 7006: ugr=b(m) */
-        double dmmr = a1 * a1 / (2.0f * ra) + 2.0f * a1 * a2 / (ra + rb) + a2 * a2 / (2.0f * rb);
-        double dmmz = a3 * a3 / (2.0f * ra) + 2.0f * a3 * a4 / (ra + rb) + a4 * a4 / (2.0f * rb);
-        double drsz = -a1 * a3 / 2.0f - (a1 * a4 * rb + a2 * a3 * ra) / (ra + rb) - a2 * a4 / 2.0f;
-        double dzsr = -a1 * a3 / 2.0f - (a1 * a4 * ra + a2 * a3 * rb) / (ra + rb) - a2 * a4 / 2.0f;
-        sumi0 = (float)(sumi0 + rho[i0] * (dmmr + dmmz));
-        sumi1 = (float)((xlamb[i0] + 2.0f * xmu[i0]) * dmmr + xmu[i0] * dmmz + sumi1);
-        sumi2 = (float)(xmu[i0] * dzsr - xlamb[i0] * drsz + sumi2);
-        (void)sumi3;
-        return (wvno * sumi1 + sumi2) / (omega * sumi0);   /* surfa.f:1186 */
+        float ugr;
+        if (rb == 0.0f) {                                /* label 7006, surfa.f:1165-1173 */
+            ugr = b[i0];
+            sumi0 = rho[i0] * 1.0e25f; sumi1 = xmu[i0] * 1.0e25f; sumi2 = 0.0f;
+            s->dcdb[i0] = -2.0f * wvno * 1.0e25f;
+        } else {
+            double dmmr = a1 * a1 / (2.0f * ra) + 2.0f * a1 * a2 / (ra + rb) + a2 * a2 / (2.0f * rb);
+            double dmmz = a3 * a3 / (2.0f * ra) + 2.0f * a3 * a4 / (ra + rb) + a4 * a4 / (2.0f * rb);
+            double smmz = ra * a3 * a3 / 2.0f + 2.0f * ra * rb * a3 * a4 / (ra + rb) + rb * a4 * a4 / 2.0f;
+            double smmr = ra * a1 * a1 / 2.0f + 2.0f * ra * rb * a1 * a2 / (ra + rb) + rb * a2 * a2 / 2.0f;
+            double drsz = -a1 * a3 / 2.0f - (a1 * a4 * rb + a2 * a3 * ra) / (ra + rb) - a2 * a4 / 2.0f;
+            double dzsr = -a1 * a3 / 2.0f - (a1 * a4 * ra + a2 * a3 * rb) / (ra + rb) - a2 * a4 / 2.0f;
+            sumi0 = (float)(sumi0 + rho[i0] * (dmmr + dmmz));
+            sumi1 = (float)((xlamb[i0] + 2.0f * xmu[i0]) * dmmr + xmu[i0] * dmmz + sumi1);
+            sumi2 = (float)(xmu[i0] * dzsr - xlamb[i0] * drsz + sumi2);
+            (void)sumi3;
+            double dldr = omegsq * (dmmr + dmmz);        /* surfa.f:1178-1184 */
+            double dldm = -wvnosq * (2.0 * dmmr + dmmz) - 2.0f * wvno * dzsr - (2.0 * smmz + smmr);
+            double dldl = -wvnosq * dmmr + 2.0f * wvno * drsz - smmz;
+            s->dcda[i0] = 2.0f * rho[i0] * a[i0] * c * dldl / wvno;
+            s->dcdb[i0] = 2.0f * rho[i0] * b[i0] * c * (dldm - 2.0 * dldl) / wvno;
+            s->dcdr[i0] = (c / wvno) * (dldr + xlamb[i0] * dldl / rho[i0] + xmu[i0] * dldm / rho[i0]);
+            ugr = (wvno * sumi1 + sumi2) / (omega * sumi0);   /* surfa.f:1186 */
+        }
+        {   /* surfa.f:1200-1249: divide by dL/dk, dwx, shift one entry down (solid top), entry 1 = the surface */
+            const int mx = mmax;                         /* (m, the entry just written, may lie above it: early exit to 7002) */
+            for (int q = (b[0] <= 0.0f) ? 2 : 1; q <= mx; ++q) {
+                double dldk = -2.0f * (wvno * sumi1 + sumi2);
+                s->dcdr[q - 1] = s->dcdr[q - 1] / dldk;
+                s->dcda[q - 1] = s->dcda[q - 1] / dldk;
+                s->dcdb[q - 1] = s->dcdb[q - 1] / dldk;
+                s->dwx[q - 1] = (s->dcda[q - 1] * 4.0f / 3.0f * b[q - 1] / a[q - 1] + s->dcdb[q - 1]) * b[q - 1];
+            }
+            s->rar_mmax = mx;
+            if (!(b[0] <= 0.0f)) {
+                for (int q = 1; q <= mx; ++q) {
+                    int i = mx - q + 1, j = i + 1;
+                    s->dcda[j - 1] = s->dcda[i - 1]; s->dcdb[j - 1] = s->dcdb[i - 1];
+                    s->dcdr[j - 1] = s->dcdr[i - 1]; s->dwx[j - 1] = s->dwx[i - 1];
+                }
+                s->rar_mmax = mx + 1;
+            }
+            s->dcda[0] = 0.0; s->dcdb[0] = 0.0; s->dcdr[0] = 0.0; s->dwx[0] = 0.0;
+        }
+        return ugr;
     }
 }
 
@@ -897,6 +980,33 @@ int surfdisp_oracle_forward(int nlay, int kind,
     s->tr_c = NULL; s->c_at = NULL;
     int st = forward_ctx(s, nlay, kind, vp, vs, rho, h, qsinv, per, nper, c_out, u_out,
                          nsolved, n_delta_out, NULL);
+    free(s);
+    return st;
+}
+
+/* The analytic partials of ONE period: a one-period solve (the reference overwrites COMMON /rar1/ at every period, so a
+ * one-period call is how a period's values are read from it, oracle/refso.py::last_partials), then dcda, dcdb, dcdr, dwx
+ * [1000] as REIGEN / LEIGEN leave them (per sublayer of the flattened, attenuated stack, shifted one entry down when the
+ * top layer is solid), *mmax = COMMON /rar/ mmax, *ndiv = the clamped COMMON /c/ ndiv.  Love leaves dcda, dwx untouched
+ * (written as zeros here).  Returns the solve's status; *c_out, *u_out = the period's phase and group velocity. */
+int surfdisp_oracle_partials(int nlay, int kind,
+                             const float *vp, const float *vs, const float *rho,
+                             const float *h, const float *qsinv, float period,
+                             double *dcda, double *dcdb, double *dcdr, double *dwx,
+                             int *mmax, int *ndiv, float *c_out, float *u_out)
+{
+    ctx_t *s = (ctx_t *)calloc(1, sizeof(ctx_t));
+    if (!s) return SURFDISP_ORACLE_EINVAL;
+    float c1 = 0.0f, u1 = 0.0f;
+    int st = forward_ctx(s, nlay, kind, vp, vs, rho, h, qsinv, &period, 1, &c1, &u1, NULL, NULL, NULL);
+    for (int i = 0; i < NSZ; ++i) {
+        dcda[i] = (kind == 2) ? s->dcda[i] : 0.0; dcdb[i] = s->dcdb[i]; dcdr[i] = s->dcdr[i];
+        dwx[i] = (kind == 2) ? s->dwx[i] : 0.0;
+    }
+    if (mmax) *mmax = s->rar_mmax;
+    if (ndiv) *ndiv = s->ndiv;
+    if (c_out) *c_out = c1;
+    if (u_out) *u_out = u1;
     free(s);
     return st;
 }

@@ -46,6 +46,13 @@ int surfdisp_oracle_forward_at(int nlay, int kind,
                                const float *per, int nper, const float *c_at,
                                float *c_out, float *u_out);
 
+/* analytic partials dc/d(a, b, rho) of ONE period as REIGEN / LEIGEN leave them in COMMON /rar1/ (double[1000] each; see the .c file) */
+int surfdisp_oracle_partials(int nlay, int kind,
+                             const float *vp, const float *vs, const float *rho,
+                             const float *h, const float *qsinv, float period,
+                             double *dcda, double *dcdb, double *dcdr, double *dwx,
+                             int *mmax, int *ndiv, float *c_out, float *u_out);
+
 /* Same signature as the reference's Fortran symbol fast_surf_ (fast_surf.f:2-5). */
 void surfdisp_oracle_fast_surf_(const int *n_layer, const int *kind,
                                 const float *vp, const float *vs, const float *rho,

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void surfdisp_layers_kernel(LayersArgs A)
     const int L = A.idesc[2];
     if (idx >= (long)A.C * L) return;
     const int c = (int)(idx / L), i = (int)(idx % L);
-    const int nin = A.idesc[0] < 10 ? A.idesc[0] : 10, ngrid = A.idesc[1], has_ref = A.idesc[3];   // (<= 10 input layers: ztop / Hl below; the host-side descriptor builder enforces it)
+    const int nin = A.idesc[0], ngrid = A.idesc[1], has_ref = A.idesc[3];
     const int *lay_i = A.idesc + 4;                    // 8 ints per input layer
     const int *coef_i = lay_i + 8 * nin;               // 8 slots per input layer
     const int *top_i = coef_i + 8 * nin;               // L ints
@@ -63,15 +63,22 @@ __global__ __launch_bounds__(256) void surfdisp_layers_kernel(LayersArgs A)
     // layer tops (a handful of layers): zbot[l] = z_start + sum of the thicknesses above
     // A row of `params` is [random-walk parameters | per-point local constants] (Model1DBatch.set_local_info): both are
     // read through slot indices.  Stack top z0 = -max(topo, 0), models.py:74.
-    double ztop[10], Hl[10];
-    double z = (lay_i[6] > 0) ? -fmax(p[lay_i[6] - 1], 0.0) : A.fdesc[0];
-    for (int l = 0; l < nin; ++l) {
-        const int hs = lay_i[8 * l + 1];
-        double H = (hs >= 0) ? p[hs] : lay_f[9 * l];
-        if (lay_i[8 * l + 2]) H = H - z;               // BottomDepth, layers.py:119-124
-        ztop[l] = z; Hl[l] = H; z += H;
-    }
-    const double zref = z;                             // top of the ReferenceMantle
+    // No register-resident arrays indexed at run time (hipcc 7.2 lowers those to s_set_gpr_idx moves and speculates guarded
+    // indexed stores: scripts/microbench/gpr_idx_guard.hip; tests/test_isa_guard.py): the top and thickness of ONE input layer
+    // are re-derived by walking the handful of layers above it.
+    const double z0 = (lay_i[6] > 0) ? -fmax(p[lay_i[6] - 1], 0.0) : A.fdesc[0];
+    auto layer_span = [&](int lq, double &zt, double &Hq) -> double {   // returns the bottom of the last input layer
+        double z = z0;
+        zt = z0; Hq = 0.0;
+        for (int l = 0; l < nin; ++l) {
+            const int hs = lay_i[8 * l + 1];
+            double H = (hs >= 0) ? p[hs] : lay_f[9 * l];
+            if (lay_i[8 * l + 2]) H = H - z;           // BottomDepth, layers.py:119-124
+            if (l == lq) { zt = z; Hq = H; }
+            z += H;
+        }
+        return z;
+    };
 
     auto grid_val = [&](int g) -> GridVal {
         GridVal v;
@@ -79,14 +86,16 @@ __global__ __launch_bounds__(256) void surfdisp_layers_kernel(LayersArgs A)
             int l = 0;
             while (l + 1 < nin && g >= lay_i[8 * l + 5]) ++l;
             const double *gf = grid_f + 9 * g;
-            v.z = ztop[l] + gf[0] * Hl[l];
+            double zt, Hq;
+            (void)layer_span(l, zt, Hq);
+            v.z = zt + gf[0] * Hq;
             double vs = 0.0;
             const int kind = lay_i[8 * l];
             if (kind == 6) {
                 const double *sc = A.scratch + ((size_t)c * 64 + (g - lay_i[8 * l + 4])) * 2;
                 vs = sc[0]; v.qs = sc[1];
             } else if (kind == 7) {
-                const double H = Hl[l];
+                const double H = Hq;
                 vs = (0.02 * (H * H) + 1.27 * H + 0.29 * 0.1) / (H + 0.29);
             } else {
                 const int nc = lay_i[8 * l + 3];
@@ -102,12 +111,14 @@ __global__ __launch_bounds__(256) void surfdisp_layers_kernel(LayersArgs A)
             const int gl = ngrid - 1;
             int l = nin - 1;
             const double *gf = grid_f + 9 * gl;
+            double zt, Hq;
+            const double zref = layer_span(l, zt, Hq);    // top of the ReferenceMantle
             double vs0 = 0.0, vp0, rho0, qs0 = 0.0;
             if (lay_i[8 * l] == 6) {
                 const double *sc = A.scratch + ((size_t)c * 64 + (gl - lay_i[8 * l + 4])) * 2;
                 vs0 = sc[0]; qs0 = sc[1];
             } else if (lay_i[8 * l] == 7) {
-                vs0 = (0.02 * (Hl[l] * Hl[l]) + 1.27 * Hl[l] + 0.29 * 0.1) / (Hl[l] + 0.29);
+                vs0 = (0.02 * (Hq * Hq) + 1.27 * Hq + 0.29 * 0.1) / (Hq + 0.29);
             } else {
                 const int nc = lay_i[8 * l + 3];
                 for (int k = 0; k < nc; ++k) {

@@ -16,8 +16,12 @@ STRICT = os.environ.get("SOAK_AGAINST") == "strict"
 T_END = time.time() + float(os.environ.get("SOAK_SECONDS", "120"))
 worst = dict(c=0.0, u=0.0)
 T_LAST = time.time()
-nstack = ncase = npat = novf = 0
+nstack = ncase = npat = novf = nbigc = nbigu = 0
 bad_cases = []
+# every offending STACK is kept (up to SOAK_KEEP), padded to a common shape, for tests/golden/make_golden_offenders.py
+KEEP = int(os.environ.get("SOAK_KEEP", "6000")); LCAP, PCAP = 48, 40
+off = dict(model=[], nlay=[], per=[], P=[], kind=[], team=[], cat=[], c=[], co=[], u=[], uo=[])
+TAG = os.environ.get("SOAK_TAG", (os.environ.get("SOAK_FAMILY") or "general") + ("_strict" if STRICT else "_oracle"))
 while time.time() < T_END:
     L = int(rng.integers(2, 48)); B = int(rng.integers(64, 2048)) * (16 if STRICT else 1); kind = int(rng.integers(1, 3))
     if os.environ.get("SOAK_KIND"):                        # one wave type only (1 Love, 2 Rayleigh)
@@ -63,6 +67,25 @@ while time.time() < T_END:
     ec = np.abs(c[ok] / co[ok] - 1) if ok.any() else np.zeros(1)
     eu = np.abs(u[ok] / uo[ok] - 1) if ok.any() else np.zeros(1)
     nstack += B; ncase += 1; npat += int((~rows).sum())
+    # per STACK: zero pattern equal, but some phase velocity off by more than the bar ("another root"), or - with every
+    # phase velocity inside the bar - some group velocity off by more than the bar
+    with np.errstate(all="ignore"):
+        e_c = np.where(ok, np.abs(c / np.where(co != 0, co, 1) - 1), 0.0)
+        e_u = np.where(ok, np.nan_to_num(np.abs(u / np.where(uo != 0, uo, 1) - 1), nan=9.0), 0.0)
+        e_u = np.where(ok & ~np.isfinite(uo) & ~np.isfinite(u), 0.0, e_u)        # NaN for NaN is agreement
+    bigc = rows & (e_c.max(axis=1) > 1e-4)
+    bigu = rows & ~bigc & (e_u.max(axis=1) > 1e-4)
+    nbigc += int(bigc.sum()); nbigu += int(bigu.sum())
+    for cat, sel in ((0, ~rows), (1, bigc), (2, bigu)):
+        for i in np.nonzero(sel)[0]:
+            if len(off["cat"]) >= KEEP: break
+            m = np.zeros((5, LCAP), np.float32); m[:, :L] = model[i]
+            pp = np.zeros(PCAP, np.float32); pp[:P] = per
+            def pad(a):
+                o = np.zeros(PCAP, np.float32); o[:P] = a[i]; return o
+            off["model"].append(m); off["nlay"].append(int(nlay[i]) if nlay is not None else L); off["per"].append(pp)
+            off["P"].append(P); off["kind"].append(kind); off["team"].append(team); off["cat"].append(cat)
+            off["c"].append(pad(c)); off["co"].append(pad(co)); off["u"].append(pad(u)); off["uo"].append(pad(uo))
     novf += int((~rows & ((st == 8) | (so == 3))).sum())     # fp32-overflow regime: either side gave up
     q = np.quantile(eu, 0.999) if eu.size > 1000 else eu.max()
     if ec.max() > 2e-5 or q > 1e-4 or (~rows).mean() > 0.02 or not np.isfinite(c).all() or not np.isfinite(u).all():
@@ -82,6 +105,13 @@ while time.time() < T_END:
         T_LAST = time.time()
         print(f"  ... {ncase} cases, {nstack} stacks, pattern mismatches {npat}, flagged {len(bad_cases)}", flush=True)
 _lib.lib().surfdisp_set_team(0)
+if off["cat"]:
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"soak_offenders_{TAG}.npz"),
+                        **{k: np.asarray(v) for k, v in off.items()})
+print(f"soak stacks with the reference's zero pattern but a phase velocity off by > 1e-4: {nbigc} ({nbigc / max(nstack, 1):.2e}); "
+      f"with every phase velocity within 1e-4 but a group velocity off by > 1e-4: {nbigu} ({nbigu / max(nstack, 1):.2e}); "
+      f"offending stacks saved: {len(off['cat'])}")
 print(f"soak ({'default vs strict mode, GPU only' if STRICT else 'HIP vs CPU oracle'}): {ncase} cases, {nstack} stacks, zero-pattern mismatches {npat} stacks "
       f"({npat / max(nstack, 1):.2e}; {novf} of them where the secular function overflowed fp32: SURFDISP_NUMERIC "
       f"or the oracle's NEVILL failure), worst c {worst['c']:.2e}, worst U(99.9%) {worst['u']:.2e}")

@@ -157,3 +157,35 @@ def test_oracle_bit_exact_on_soak_family_fixtures(ref_families, family):
     d = ref_families[family]
     c, u, st = cport.forward_batch(d["model"], d["periods"], d["kind"], nlay=d["nlay"], nthreads=4)
     assert np.array_equal(c, d["c"]) and np.array_equal(u, d["u"], equal_nan=True)
+
+
+# ---- analytic partials: the oracle against the reference's own COMMON /rar1/ (tests/golden/make_golden_partials.py)
+PARTIALS = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "ref_partials.npz"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in PARTIALS["names"]])
+@pytest.mark.parametrize("wave", ["R", "L"])
+def test_oracle_partials_bit_exact_vs_reference_common_block(name, wave):
+    """dcda, dcdb, dcdr, dwx of every sublayer as REIGEN / LEIGEN leave them (surfa.f:1133-1135, 1182-1184, 1204-1207;
+    Love 511-512, 564-565, 582-583), one-period calls, first mmax entries of the block: bit for bit."""
+    kind = 2 if wave == "R" else 1
+    m = PARTIALS[f"{name}_model"]
+    blk, meta = PARTIALS[f"{name}_{wave}_rar1"], PARTIALS[f"{name}_{wave}_meta"]
+    nz = 0
+    for ip, T in enumerate(PARTIALS["periods"]):
+        o = cport.partials(m[0], m[1], m[2], m[3], m[4], T, kind)
+        c, u, mm, ndiv = meta[ip]
+        assert np.float32(o["c"]) == np.float32(c) and o["ndiv"] == int(ndiv)
+        if c <= 0:
+            continue
+        assert o["mmax"] == int(mm)
+        if not (name.startswith("water") and kind == 2):           # (complex water-layer terms: last-bit differences)
+            assert np.float32(o["u"]) == np.float32(u)
+        for i, k in enumerate(("dcda", "dcdb", "dcdr", "dwx")):
+            ref = blk[ip, i, :int(mm)]
+            if name.startswith("water") and kind == 2:
+                assert np.abs(o[k][:int(mm)] - ref).max() <= 2e-6 * max(np.abs(ref).max(), 1e-30)
+            else:
+                assert np.array_equal(o[k][:int(mm)], ref), (name, wave, T, k)
+            nz += int(np.count_nonzero(ref))
+    assert nz > 50
