@@ -406,9 +406,22 @@ def workload_grid(rt, args, steps=None, warmup=None):
     pts, chains = int(os.environ.get("BENCH_GRID_POINTS", "512")), int(os.environ.get("BENCH_GRID_CHAINS", "50"))
     K = steps if steps is not None else args.steps
     W = warmup if warmup is not None else args.warmup
-    mb, c_obs, unc = _mcmc_setup(rt, pts, chains)
     rep = lambda a: np.repeat(a, chains, axis=0)
-    mc = MetropolisBatch(mb.spec, mb.to_model, MCMC_PERIODS, rep(c_obs), rep(unc), device=rt.dev, seed=7 + rt.rank)
+    total = int(getattr(args, "total_points", 0) or 0)
+    if total:
+        # strong scaling: one grid for any rank count.  Every rank derives the observations of the WHOLE grid from the same
+        # seed and keeps its block; its chains carry their index in the whole sampler (chain0), which keys the random streams
+        from pysurfinv_amd.settings import synthetic_observations
+        from pysurfinv_amd.shard import shard_range
+        lo, hi = shard_range(total, rt.rank, rt.world)
+        pts = hi - lo
+        mb, c_all, unc_all = synthetic_observations(total, rt.dev, seed=100)
+        c_obs, unc = c_all[lo:hi], unc_all[lo:hi]
+        mc = MetropolisBatch(mb.spec, mb.to_model, MCMC_PERIODS, rep(c_obs), rep(unc), device=rt.dev, seed=7)
+        mc._chain0 = lo * chains
+    else:
+        mb, c_obs, unc = _mcmc_setup(rt, pts, chains)
+        mc = MetropolisBatch(mb.spec, mb.to_model, MCMC_PERIODS, rep(c_obs), rep(unc), device=rt.dev, seed=7 + rt.rank)
     C = pts * chains
     state = {}
 
@@ -474,10 +487,14 @@ def workload_grid(rt, args, steps=None, warmup=None):
                                     "kernel's duration includes the time it shares SIMDs with the other group's kernels)" if cg is not None else "")},
             "roofline": leg_roofline("grid", kms[1], (20 * L + 4 * len(MCMC_PERIODS)) * Cl, team=team,
                                      chip=(cg.G, elapsed / K * 1e3) if cg is not None else None),
-            "value": rt.world * C * K / elapsed, "forward_solves_per_s": rt.world * C * K / elapsed,
-            "ms_per_step": elapsed / K * 1e3, "steps": K, "warmup": W, "n_gpus": rt.world, "scaling": "weak",
-            "config": {"workload": "BASELINE configs[3] share per GPU: 512 points x 50 chains, 96-layer continental model, "
-                                   "19 periods, Rayleigh phase-only misfit, default scan",
+            "value": (total * chains if total else rt.world * C) * K / elapsed,
+            "forward_solves_per_s": (total * chains if total else rt.world * C) * K / elapsed,
+            "ms_per_step": elapsed / K * 1e3, "steps": K, "warmup": W, "n_gpus": rt.world, "scaling": "strong" if total else "weak",
+            "config": {"workload": (f"BASELINE configs[3], the WHOLE grid on every rank count: {total} points x {chains} chains dealt "
+                                    f"to {rt.world} rank(s) in contiguous blocks, " if total else
+                                    "BASELINE configs[3] share per GPU: 512 points x 50 chains, ") +
+                                   "96-layer continental model, 19 periods, Rayleigh phase-only misfit, default scan",
+                       "total_points": total if total else rt.world * pts,
                        "lock_step": ("fused: propose kernel, parameters->stacks, prep / root search / finish, accept kernel"
                                      if fused else "torch glue around the solver"),
                        "chain_groups": cg.G if cg is not None else 1,
@@ -607,6 +624,11 @@ def main():
                     help="all (default): the forward headline line + short legs of the other BASELINE configs inside it; "
                          "a single name: only that workload, as the line itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--total-points", type=int, default=0,
+                    help="--workload grid only: STRONG scaling - the SAME grid of this many surface points (4096 = BASELINE "
+                         "configs[3]) x 50 chains is dealt to the ranks in contiguous blocks (1 GPU: all of it, 8 GPUs: 512 "
+                         "points each); every point has the same observations and every chain the same random stream whatever "
+                         "the rank count.  0 (default): weak scaling, 512 points per rank")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -620,6 +642,9 @@ def main():
         # a solver call (tests/test_bench_launch.py runs it on CPU with BENCH_REHEARSAL=cpu)
         mine = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
         mine["pid"], mine["ppid"] = os.getpid(), os.getppid()
+        if args.total_points:                                  # the block of the strong-scaling grid this rank would own
+            from pysurfinv_amd.shard import shard_range
+            mine["points"] = list(shard_range(args.total_points, rt.rank, rt.world))
         ranks = [mine]
         if rt.dist is not None:
             ranks = [None] * rt.world

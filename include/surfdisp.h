@@ -70,6 +70,13 @@ extern "C" {
                                      * arithmetic, overflow points and evaluation sequence, several times slower.  The default
                                      * mode agrees with it to ~1e-6 on c; use it to check that on your own models
                                      * (tests/test_gpu_parity.py does, at the bench size), not in production. */
+#define SURFDISP_KERN_REFCOORD 0x400 /* OR into `kind` of surfdisp_forward_kernels_device: the analytic partials in the REFERENCE's
+                                     * coordinates - with respect to the earth-flattened, attenuation-corrected layer values the
+                                     * eigenproblem is solved for (no chain factors of calcul.f:122-126 / flat1.f:44-62), i.e. what
+                                     * REIGEN / LEIGEN leave in COMMON /rar1/ (surfa.f:1133-1135, 1182-1184, 1204-1207; Love 511-512,
+                                     * 564-565, 582-583) summed over each layer's sublayers; a water layer's own share (which the
+                                     * reference does not form) is left out.  The verification mode the reference-generated fixture
+                                     * tests/golden/ref_partials.npz is compared in; ignored by the other entries. */
 #define SURFDISP_PHASE_ONLY    0x10 /* OR into `kind` of the batched entries: phase velocities only
                                      * (what Point.misfit consumes, point.py:18); u is not written
                                      * and may be NULL */
@@ -177,8 +184,9 @@ int surfdisp_stream_wait_event(void *stream, void *event);
  *          calcul.f:122-126 and of the earth flattening flat1.f:44-62 are applied); zero for water
  *          layers, layers below the effective half space and unsolved periods.  dcda, dcdr may be
  *          NULL; Love has no dcda (written as zeros if given).  Workspace: surfdisp_kernels_workspace_bytes
- *          (the partials are accumulated in a layer-major scratch inside it and transposed into the rows at the end:
- *          coalesced); a workspace of only surfdisp_workspace_bytes is accepted and takes the direct, slower route. */
+ *          (every layer's share is stored once, unscaled, in a layer-major scratch inside it - coalesced - and a
+ *          transposition kernel applies the common factor 1 / (dL/dk) and writes whole rows); a workspace of only
+ *          surfdisp_workspace_bytes is accepted and takes the direct, slower route (same values, bit for bit). */
 size_t surfdisp_kernels_workspace_bytes(int B, int Lmax, int P);
 int surfdisp_forward_kernels_device(void *stream, int B, int Lmax, const int *nlay,
                                     const float *model, int P, const float *per, int kind,

@@ -54,12 +54,28 @@ typedef struct {
     /* developer trace of the scan of one period (surfdisp_oracle_scan_trace; not in the reference) */
     int tr_k, tr_cap, tr_n, tr_extra;
     float *tr_c, *tr_d; int *tr_mm;
+    /* developer aid (surfdisp_oracle_bracket_profile): nsub > 0 - once period tr_k's bracket is found, the secular function
+     * at nsub + 1 equidistant points across it with the layer dropping frozen (idrop = 1), as NEVILL sees it */
+    int tr_nsub;
     /* test hook (surfdisp_oracle_forward_at; not in the reference): phase velocities at which the ellipticity
      * and the group velocity of each period are evaluated instead of the oracle's own roots */
     const float *c_at;
 } ctx_t;
 
 static inline float sgn1(float x) { return copysignf(1.0f, x); } /* SIGN(1.,x) */
+
+/* NOT the reference: "equally valid" fp32 evaluations of the reference's own formulas, used only by scripts/soak.py to tell
+ * whether a root or a sign is DEFINED by the formulas or by the rounding of one particular libm (a result that moves by more
+ * than the parity bar under such a variant cannot be reproduced by any other arithmetic than the reference's own, bit for bit):
+ *   bit 0: e^x of the secular functions as exp2f(x log2 e) instead of expf (the hyperbolic functions of thin evanescent layers
+ *          are differences of two such values: (e^x - e^-x)/2 for |x| << 1 is cancellation noise of the exponential's last bit)
+ *   bit 1: the earth-flattening factors from double-precision log / pow rounded once (flat1.f:44-56 differences nearly equal powf
+ *          values: one ulp of powf moves a sub-kilometre layer's density by 4e-4) */
+static int g_variant = 0;
+void surfdisp_oracle_set_variant(int v) { g_variant = v; }
+static inline float exp_v(float x) { return (g_variant & 1) ? exp2f(x * 1.44269504f) : expf(x); }
+static inline float log_v(float x) { return (g_variant & 2) ? (float)log((double)x) : logf(x); }
+static inline float pow_v(float x, float y) { return (g_variant & 2) ? (float)pow((double)x, (double)y) : powf(x, y); }
 
 /* ---------------------------------------------------------------- flat1.f:2-73
  * Earth-flattening (Biswas 1972), in place on the first n layers. */
@@ -79,10 +95,10 @@ static void flat1(float *h, float *ro, float *vp, float *vs, int n, int kind)
     }
     for (int i = 0; i < nm; ++i) {          /* flat1.f:41-56 */
         int ii = i + 1;
-        float fltd = logf(hh[i] / hh[ii]);
+        float fltd = log_v(hh[i] / hh[ii]);
         float dif = (1.0f / hh[ii] - 1.0f / hh[i]) * a / fltd;
-        float difr = powf(hh[i], pwr) - powf(hh[ii], pwr);
-        float qqq = difr / (fltd * powf(a, pwr) * pwr);
+        float difr = pow_v(hh[i], pwr) - pow_v(hh[ii], pwr);
+        float qqq = difr / (fltd * pow_v(a, pwr) * pwr);
         ro[i] = ro[i] * qqq;
         vp[i] = vp[i] * dif;
         vs[i] = vs[i] * dif;
@@ -90,10 +106,10 @@ static void flat1(float *h, float *ro, float *vp, float *vs, int n, int kind)
     float fact = a / hh[n - 1];             /* flat1.f:58-62 half space */
     vp[n - 1] = vp[n - 1] * fact;
     vs[n - 1] = vs[n - 1] * fact;
-    ro[n - 1] = ro[n - 1] * powf(1.0f / fact, pwr);
+    ro[n - 1] = ro[n - 1] * pow_v(1.0f / fact, pwr);
     float z0 = 0.0f;
     for (int i = 1; i < n; ++i) {           /* flat1.f:65-68 */
-        float z1 = a * logf(a / hh[i]);
+        float z1 = a * log_v(a / hh[i]);
         h[i - 1] = z1 - z0;
         z0 = z1;
     }
@@ -137,7 +153,7 @@ static float dltar1(const ctx_t *s, float c, float t)
         if (rb < 0.1e-20f || c == b[m]) {          /* label 1221 */
             y = -wvno * d[m]; z = 0.0f; cosq = 1.0f;
         } else if (c < b[m]) {                     /* label 1209 */
-            float exqp = expf(q), exqm = 1.0f / exqp;
+            float exqp = exp_v(q), exqm = 1.0f / exqp;
             y = (exqp - exqm) / (2.0f * rb);
             z = -rb * rb * y;
             cosq = (exqp + exqm) / 2.0f;
@@ -182,8 +198,8 @@ static float dltar4(const ctx_t *s, float c, float t, int mup)
                 if (fabsf(ra) < accur || ra == 0.0f) {
                     sinpr = wvno * d[m]; cosp = 1.0f;
                 } else if (ra < 0.0f) {
-                    sinpr = (expf(pm) - expf(-pm)) / (2.0f * ra);
-                    cosp = 0.5f * (expf(pm) + expf(-pm));
+                    sinpr = (exp_v(pm) - exp_v(-pm)) / (2.0f * ra);
+                    cosp = 0.5f * (exp_v(pm) + exp_v(-pm));
                 } else {
                     sinpr = sinf(pm) / ra;
                     cosp = cosf(pm);
@@ -202,9 +218,9 @@ static float dltar4(const ctx_t *s, float c, float t, int mup)
                 float qm = wvno * rb * d[m];
                 float rsinp, sinpr, cosp, rsinq, sinqr, cosq;
                 if (ra < 0.0f) {
-                    rsinp = -ra * 0.5f * (expf(pm) - expf(-pm));
+                    rsinp = -ra * 0.5f * (exp_v(pm) - exp_v(-pm));
                     sinpr = -rsinp / (ra * ra);
-                    cosp = 0.5f * (expf(pm) + expf(-pm));
+                    cosp = 0.5f * (exp_v(pm) + exp_v(-pm));
                 } else if (ra == 0.0f) {
                     rsinp = 0.0f; sinpr = wvno * d[m]; cosp = 1.0f;
                 } else {
@@ -219,9 +235,9 @@ static float dltar4(const ctx_t *s, float c, float t, int mup)
                     sinqr = rsinq / (rb * rb);
                     cosq = cosf(qm);
                 } else {
-                    rsinq = -rb * 0.5f * (expf(qm) - expf(-qm));
+                    rsinq = -rb * 0.5f * (exp_v(qm) - exp_v(-qm));
                     sinqr = -rsinq / (rb * rb);
-                    cosq = 0.5f * (expf(qm) + expf(-qm));
+                    cosq = 0.5f * (exp_v(qm) + exp_v(-qm));
                 }
                 float rr = rsinp * rsinq, ss = sinpr * sinqr, cc = cosp * cosq;
                 float rs1 = rsinp * cosq, rs2 = sinqr * cosp, rs3 = sinpr * cosq, rs4 = rsinq * cosp;
@@ -914,6 +930,15 @@ static int forward_ctx(ctx_t *s, int nlay, int kind,
             s->idrop = 0;
             del2 = dltar(s, c2, t1, ifunc);
             if (tracing && s->tr_n < s->tr_cap) { s->tr_c[s->tr_n] = c2; s->tr_d[s->tr_n] = del2; s->tr_mm[s->tr_n++] = s->mmax; }
+            if (tracing && s->tr_nsub > 0 && sgn1(del1) != sgn1(del2)) {
+                s->tr_n = 0;
+                s->idrop = 1;
+                for (int e = 0; e <= s->tr_nsub && s->tr_n < s->tr_cap; ++e) {
+                    const float cx = c1 + (c2 - c1) * ((float)e / (float)s->tr_nsub);
+                    s->tr_c[s->tr_n] = cx; s->tr_d[s->tr_n] = dltar(s, cx, t1, ifunc); s->tr_mm[s->tr_n++] = s->mmax;
+                }
+                return SURFDISP_ORACLE_OK;
+            }
             if (tracing && sgn1(del1) != sgn1(del2)) {          /* keep scanning tr_extra points past the bracket */
                 float cx = c2;
                 for (int e = 0; e < s->tr_extra && s->tr_n < s->tr_cap; ++e) {
@@ -982,6 +1007,24 @@ int surfdisp_oracle_forward(int nlay, int kind,
                          nsolved, n_delta_out, NULL);
     free(s);
     return st;
+}
+
+/* developer aid: the secular function across the bracket of period k (nsub + 1 equidistant points, frozen layer dropping);
+ * returns the number of points written (0: no bracket) */
+int surfdisp_oracle_bracket_profile(int nlay, int kind,
+                                    const float *vp, const float *vs, const float *rho,
+                                    const float *h, const float *qsinv,
+                                    const float *per, int nper, int k, int nsub,
+                                    float *c_tr, float *d_tr, int *mm_tr, int cap)
+{
+    ctx_t *s = (ctx_t *)calloc(1, sizeof(ctx_t));
+    if (!s) return 0;
+    float cbuf[SURFDISP_NPER_MAX], ubuf[SURFDISP_NPER_MAX];
+    s->tr_k = k; s->tr_cap = cap; s->tr_extra = 0; s->tr_nsub = nsub; s->tr_c = c_tr; s->tr_d = d_tr; s->tr_mm = mm_tr;
+    forward_ctx(s, nlay, kind, vp, vs, rho, h, qsinv, per, nper, cbuf, ubuf, NULL, NULL, NULL);
+    const int n = (s->tr_nsub > 0 && s->tr_n == nsub + 1) ? s->tr_n : 0;
+    free(s);
+    return n;
 }
 
 /* The analytic partials of ONE period: a one-period solve (the reference overwrites COMMON /rar1/ at every period, so a

@@ -33,6 +33,12 @@ int surfdisp_oracle_scan_trace(int nlay, int kind,
                                const float *per, int nper, int k, int extra,
                                float *c_tr, float *d_tr, int *mm_tr, int cap);
 
+int surfdisp_oracle_bracket_profile(int nlay, int kind,
+                                    const float *vp, const float *vs, const float *rho,
+                                    const float *h, const float *qsinv,
+                                    const float *per, int nper, int k, int nsub,
+                                    float *c_tr, float *d_tr, int *mm_tr, int cap);
+
 int surfdisp_oracle_forward_dbg(int nlay, int kind,
                                 const float *vp, const float *vs, const float *rho,
                                 const float *h, const float *qsinv,
@@ -52,6 +58,11 @@ int surfdisp_oracle_partials(int nlay, int kind,
                              const float *h, const float *qsinv, float period,
                              double *dcda, double *dcdb, double *dcdr, double *dwx,
                              int *mmax, int *ndiv, float *c_out, float *u_out);
+
+/* NOT the reference: switches the whole library to an "equally valid" fp32 evaluation of the reference's formulas (bit 0:
+ * exponentials of the secular functions through exp2f; bit 1: flattening factors from double-precision log / pow); 0 = the
+ * reference's arithmetic.  For scripts/soak.py's classification of mismatches only; never set by the tests that pin parity. */
+void surfdisp_oracle_set_variant(int v);
 
 /* Same signature as the reference's Fortran symbol fast_surf_ (fast_surf.f:2-5). */
 void surfdisp_oracle_fast_surf_(const int *n_layer, const int *kind,

@@ -21,6 +21,7 @@ PIPELINED = 0x40
 EXACTSCAN = 0x80        # every grid point of the scan (Rayleigh: the default anyway; Love: switches the certified coarse scan off)
 FASTSCAN = 0x100        # opt-in heuristic scan (include/surfdisp.h)
 STRICT = 0x200          # verification mode: every stack through the statement-by-statement kernel
+KERN_REFCOORD = 0x400   # surfdisp_forward_kernels_device: partials in the reference's coordinates (flattened, attenuated layer values)
 NPER_MAX, NLAY_MAX = 200, 200
 
 # every symbol include/surfdisp.h declares

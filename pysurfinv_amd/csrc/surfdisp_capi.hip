@@ -26,6 +26,11 @@ struct EnvKnobs {
     float refine_wtol = 1.2e-3f;  // SURFDISP_WTOL
     float refine_atol = 1.0e-6f;  // SURFDISP_ATOL
     float phimax = 0.7853982f;    // SURFDISP_SCAN_PHASE (fast scan only; developer knob)
+    float ambig = 3.0e-5f;        // SURFDISP_AMBIG (developer knob): scan trials below this fraction of their terms' magnitude are
+                                  // evaluated again with the reference's arithmetic (0 = off)
+    float ell_ambig = 3.0e-3f;    // SURFDISP_ELL_AMBIG (developer knob): ellipticity closures below this fraction of their terms' magnitude are
+                                  // evaluated again with the reference's arithmetic (0 = off)
+    float phimulti = 1.0f;        // SURFDISP_PHIMULTI (developer knob): vertical-phase growth (rad) across a bracket beyond which NEVILL refines it
     bool fastscan = false;        // SURFDISP_FASTSCAN=1: opt every call of the process into the heuristic scan
     int device = 0;               // SURFDISP_DEVICE (fast_surf_)
     int balance = -1;             // SURFDISP_BALANCE (developer knob): wavefront priority by progress, -1 = automatic
@@ -50,6 +55,9 @@ struct EnvKnobs {
         if (const char *e = getenv("SURFDISP_WTOL")) refine_wtol = (float)atof(e);
         if (const char *e = getenv("SURFDISP_ATOL")) refine_atol = (float)atof(e);
         if (const char *e = getenv("SURFDISP_SCAN_PHASE")) phimax = (float)atof(e);
+        if (const char *e = getenv("SURFDISP_AMBIG")) ambig = (float)atof(e);
+        if (const char *e = getenv("SURFDISP_PHIMULTI")) phimulti = (float)atof(e);
+        if (const char *e = getenv("SURFDISP_ELL_AMBIG")) ell_ambig = (float)atof(e);
         if (const char *e = getenv("SURFDISP_FASTSCAN")) fastscan = atoi(e) != 0;
         if (const char *e = getenv("SURFDISP_DEVICE")) device = atoi(e);
         if (const char *e = getenv("SURFDISP_BALANCE")) balance = atoi(e);
@@ -78,7 +86,7 @@ void set_err(const char *fmt, const char *a = "", const char *b = "")
     } while (0)
 
 constexpr int SD_KIND_FLAGS = SURFDISP_PHASE_ONLY | SURFDISP_INDEPENDENT | SURFDISP_PIPELINED | SURFDISP_EXACTSCAN |
-                             SURFDISP_FASTSCAN | SURFDISP_STRICT;
+                             SURFDISP_FASTSCAN | SURFDISP_STRICT | SURFDISP_KERN_REFCOORD;
 
 size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -87,6 +95,7 @@ struct Carve {
     int *nl, *nsolved, *hist;
     float *fsafe, *ovf;
     int *fb_count, *fb_list;
+    int *amb_count;       // [1] scan trials evaluated again with the reference's arithmetic (behind fb_count: zeroed with it)
     size_t total;
 };
 
@@ -105,7 +114,7 @@ Carve carve(void *base, int B, int Lmax, int P)
     c.nsolved = reinterpret_cast<int *>(p + off);   off += align_up((size_t)B * sizeof(int));
     c.fsafe = reinterpret_cast<float *>(p + off);   off += align_up((size_t)B * sizeof(float));
     c.ovf = reinterpret_cast<float *>(p + off);     off += align_up((size_t)3 * B * sizeof(float));
-    c.fb_count = reinterpret_cast<int *>(p + off);  off += align_up(sizeof(int));
+    c.fb_count = reinterpret_cast<int *>(p + off);  c.amb_count = c.fb_count + 1;  off += align_up(3 * sizeof(int));
     c.fb_list = reinterpret_cast<int *>(p + off);   off += align_up((size_t)P * B * sizeof(int));
     c.total = off;
     return c;
@@ -255,7 +264,9 @@ size_t surfdisp_workspace_bytes(int B, int Lmax, int P)
 size_t surfdisp_kernels_workspace_bytes(int B, int Lmax, int P)
 {
     if (B < 1 || Lmax < 2 || P < 1) return 0;
-    return align_up(carve(nullptr, B, Lmax, P).total) + (size_t)3 * Lmax * P * B * sizeof(float);
+    // + per unit its factor 1 / (dL/dk) and the deepest layer it wrote
+    return align_up(carve(nullptr, B, Lmax, P).total) + align_up((size_t)3 * Lmax * P * B * sizeof(float)) +
+           2 * align_up((size_t)P * B * sizeof(float));
 }
 
 // introspection: how many stacks (or (stack, period) units in independent mode) the last solve that used this
@@ -291,6 +302,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     const EnvKnobs &kn = knobs();
     const bool strict = (kind & SURFDISP_STRICT) != 0;
     const bool exactscan = (kind & SURFDISP_EXACTSCAN) != 0;
+    const bool kern_raw = (kind & SURFDISP_KERN_REFCOORD) != 0;
     bool fastscan = ((kind & SURFDISP_FASTSCAN) != 0 || kn.fastscan) && !exactscan && !strict;
     kind &= ~SD_KIND_FLAGS;
     // Love: the coarse scan with its Sturm-count certificate (phase_body, CERT) is the DEFAULT - it returns the bracket the
@@ -335,16 +347,20 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
 #endif
     if (use_rows) { ph.msrc = w.rows; ph.ms_b = 9L * Lmax; ph.ms_f = Lmax; ph.ms_i = 1; }
     else          { ph.msrc = w.mdl;  ph.ms_b = 1;         ph.ms_f = (long)Lmax * B; ph.ms_i = B; }
-    ph.hist = ell_k ? w.hist : nullptr;
+    // (two-lane teams compute their ellipticities themselves but record the history too: the pairs whose closure cancels
+    // are redone by the ellipticity kernel)
+    const bool ell_fix = ell_in && !strict && kn.ell_kernel != 0 && kn.ell_ambig > 0.0f;
+    ph.hist = (ell_k || ell_fix) ? w.hist : nullptr;
     ph.lockstep = kn.lockstep >= 0 ? kn.lockstep : 1;
+    ph.ambig = kn.ambig; ph.phimulti = kn.phimulti; ph.amb_count = w.amb_count; ph.ell_ambig = ell_fix ? kn.ell_ambig : 0.0f;
     SD_HIP(sd::launch_phase(s, kind, G, indep, ph));
     // the exact fallback re-solves what the production kernel listed (normally nothing: idle blocks exit at once)
     ph.overlap = 0; ph.fast = 0;
     if (ell_k) ph.ratio = w.ratio;                         // ... with its ellipticities in-kernel (marked -1 in hist)
     SD_HIP(sd::launch_phase_exact(s, kind, indep, ph));
     if (ev) SD_HIP(hipEventRecord(ev[2], s));              // [ev1, ev2] = the root search (+ its idle fallback launch)
-    if (ell_k) {
-        sd::EllipArgs ea{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.hist, w.nsolved, w.ratio};
+    if (ell_k || ell_fix) {
+        sd::EllipArgs ea{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.hist, w.nsolved, w.ratio, kn.ell_ambig, ell_k ? 0 : 1, w.amb_count};
         SD_HIP(sd::launch_ellip(s, ea));
     }
 #ifdef SD_WAVECLOCK
@@ -353,16 +369,21 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     double *gdbg = g_dbg.load(std::memory_order_relaxed);
 #endif
     // analytic partials: through the layer-major scratch when the caller's workspace has room for it
-    float *kscr = nullptr;
-    if (kb && workspace_bytes >= surfdisp_kernels_workspace_bytes(B, Lmax, P))
-        kscr = reinterpret_cast<float *>(static_cast<char *>(workspace) + align_up(w.total));
-    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, gdbg, kb, ka, kr, kscr};
+    float *kscr = nullptr, *kscale = nullptr;
+    int *khs = nullptr;
+    if (kb && workspace_bytes >= surfdisp_kernels_workspace_bytes(B, Lmax, P)) {
+        char *q = static_cast<char *>(workspace) + align_up(w.total);
+        kscr = reinterpret_cast<float *>(q);    q += align_up((size_t)3 * Lmax * P * B * sizeof(float));
+        kscale = reinterpret_cast<float *>(q);  q += align_up((size_t)P * B * sizeof(float));
+        khs = reinterpret_cast<int *>(q);
+    }
+    sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, gdbg, kb, ka, kr, kscr, kscale, khs,
+                     kern_raw ? 1 : 0};
     if (!phase_only) SD_HIP(sd::launch_group(s, kind, ga));
     if (!phase_only && kscr) {
-        const size_t arr = (size_t)Lmax * P * B;
-        SD_HIP(sd::launch_kern_transpose(s, kscr, kb, B, P, Lmax));
-        if (ka) SD_HIP(sd::launch_kern_transpose(s, kscr + arr, ka, B, P, Lmax));
-        if (kr) SD_HIP(sd::launch_kern_transpose(s, kscr + 2 * arr, kr, B, P, Lmax));
+        // one launch for the three arrays: factor 1 / (dL/dk), zeros below each unit's half space, whole rows
+        sd::KernTransposeArgs ta{B, P, Lmax, kind, kscr, kscale, khs, kb, ka, kr};
+        SD_HIP(sd::launch_kern_transpose(s, ta));
     }
     if (ratio && kind != SURFDISP_KIND_RAYLEIGH) SD_HIP(hipMemsetAsync(ratio, 0, (size_t)B * P * sizeof(float), s));   // Love: zeros
     sd::FinishArgs fa{B, P, w.ct, phase_only ? nullptr : w.ut, c, phase_only ? nullptr : u,

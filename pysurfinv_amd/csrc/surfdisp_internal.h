@@ -54,6 +54,11 @@ struct PhaseArgs {
     // computed in the kernel itself (exact fallback)
     int *hist;
     int lockstep;         // the teams of a wavefront refine and end their periods together (see the root search's main loop)
+    float ambig;          // a scan trial with |value| below this fraction of its terms' magnitude is evaluated again with the
+                          // reference's own arithmetic (0: never)
+    float phimulti;       // a bracket across which the vertical phase grows by more than this (rad) goes to NEVILL
+    int *amb_count;       // nullptr, or [2]: number of scan trials / of ellipticities evaluated again (statistics)
+    float ell_ambig;      // in-kernel ellipticity passes: a closure below this fraction of its terms marks the pair for the ellipticity kernel
 #ifdef SD_WAVECLOCK
     unsigned long long *wclk;   // developer build: [waves][2] s_memrealtime at wavefront start / end
 #endif
@@ -70,7 +75,17 @@ struct GroupArgs {
     float *u;             // [P][B]
     double *dbg;          // nullptr, or [B][P][16] intermediate values (developer builds)
     float *kb, *ka, *kr;  // nullptr, or [B][P][Lmax] analytic partials dc/dVs, dc/dVp, dc/drho
-    float *kscr;          // nullptr, or the layer-major scratch [3][Lmax][P][B] they are accumulated in (coalesced)
+    float *kscr;          // nullptr, or the layer-major scratch [3][Lmax][P][B] the unscaled shares are stored in (coalesced)
+    float *kscale;        // with kscr: [P][B] the unit's factor 1 / (dL/dk), 0 = no partials (unsolved / invalid unit)
+    int *khs;             // with kscr: [P][B] deepest layer the unit wrote (-1: none)
+    int kraw;             // SURFDISP_KERN_REFCOORD: partials in the reference's coordinates (unit chain factors)
+};
+struct KernTransposeArgs {
+    int B, P, Lmax, kind;
+    const float *kscr;    // [3][Lmax][P][B]
+    const float *kscale;  // [P][B]
+    const int *khs;       // [P][B]
+    float *kb, *ka, *kr;  // the caller's [B][P][Lmax] rows (ka, kr may be nullptr)
 };
 
 struct EllipArgs {
@@ -82,6 +97,9 @@ struct EllipArgs {
     const int *hist;      // [P][B], see PhaseArgs
     const int *nsolved;   // [B]
     float *ratio;         // [P][B]
+    float ell_ambig;      // a closure below this fraction of its terms: both passes again with the reference's arithmetic (0: never)
+    int only_flagged;     // 1: the root search wrote the ellipticities itself; redo only the pairs it marked (bit 30 of hist)
+    int *amb_count;       // nullptr, or [2] statistics, see PhaseArgs
 };
 hipError_t launch_ellip(hipStream_t s, const EllipArgs &a);
 
@@ -150,7 +168,7 @@ size_t phase_exact_lds_bytes(int Lmax, int G, int kind);
 int phase_exact_team(int Lmax, int kind);                // lanes per stack of the exact fallback kernel
 hipError_t launch_phase_exact(hipStream_t s, int kind, bool independent, const PhaseArgs &a);
 hipError_t launch_finish(hipStream_t s, const FinishArgs &a);
-hipError_t launch_kern_transpose(hipStream_t s, const float *scr, float *out, int B, int P, int Lmax);
+hipError_t launch_kern_transpose(hipStream_t s, const KernTransposeArgs &a);
 hipError_t launch_prep(hipStream_t s, int kind, const PrepArgs &a);
 hipError_t launch_phase(hipStream_t s, int kind, int G, bool independent, const PhaseArgs &a);
 hipError_t launch_group(hipStream_t s, int kind, const GroupArgs &a);

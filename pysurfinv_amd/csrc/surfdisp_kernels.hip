@@ -137,7 +137,7 @@ SD_HD inline void prep_stack(const PrepArgs &A, const int b)
         A.ovf[(size_t)B + b] = 2.0f * logf(fmaxf(rhomax, 1.0e-30f));
         A.ovf[2 * (size_t)B + b] = 4.0f * logf(fmaxf(2.0f * bmax * bmax, 1.0e-30f));
     }
-    if (A.fb_count && b == 0) *A.fb_count = 0;                 // empty list of stacks for the exact fallback
+    if (A.fb_count && b == 0) { A.fb_count[0] = 0; A.fb_count[1] = 0; A.fb_count[2] = 0; }   // empty list of stacks for the exact fallback; [1], [2]: scan trials / ellipticities re-evaluated
     if (A.nsolved_init) A.nsolved_init[b] = ok ? A.P : 0;      // independent mode: reduced with atomicMin
 }
 
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void surfdisp_prep_kernel(PrepArgs A)
             A.ovf[(size_t)B + b] = 2.0f * logf(fmaxf(rhomax, 1.0e-30f));
             A.ovf[2 * (size_t)B + b] = 4.0f * logf(fmaxf(2.0f * bmax * bmax, 1.0e-30f));
         }
-        if (A.fb_count && b == 0) *A.fb_count = 0;
+        if (A.fb_count && b == 0) { A.fb_count[0] = 0; A.fb_count[1] = 0; A.fb_count[2] = 0; }
     }
 }
 
@@ -466,8 +466,10 @@ __device__ __forceinline__ void ray_step(RState &s, const RTrial &t, const RLyr 
 // half-space closure, surfa.f:340-354, on (b1, rhoc h2..h4, rhoc^2 h5) with rhoc of the last layer gone through
 // (a itself is not needed: every occurrence is a^2, available as 1/ia2); A = the values of layer mmax - 1, rho_last its
 // density, rho_prev the density of layer mmax - 2 (0 when there is none: the state is in that layer's scale)
+// *mag (if given): the sum of the magnitudes of the closure's five terms - |value| far below it means the value is the
+// remainder of a cancellation, i.e. its SIGN is within the rounding of this arithmetic (the scan's ambiguity test)
 __device__ __forceinline__ float ray_close(const RState &s, const RTrial &t, const RLyr &A, const float rho_last,
-                                           const float rho_prev, const int start)
+                                           const float rho_prev, const int start, float *mag = nullptr, const bool want_mag = true)
 {
     const float csq = t.csq, icsq = t.icsq;
     const float sv = A.sv, ia2 = A.ia2;
@@ -492,13 +494,15 @@ __device__ __forceinline__ float ray_close(const RState &s, const RTrial &t, con
     const float h15 = rba * (irho * irho) * ia2 * icsq * ig;         // rba/(rho a)^2/c^2/g
     const float h12 = -ig * it12;
     const float bb1 = h11 * s.b1 + rhoc * (h12 * s.h2 + 2.0f * h13 * s.h3 + h14 * s.h4 + rhoc * (h15 * s.h5));
+    if (mag && want_mag) *mag = fabsf(h11 * s.b1) + fabsf(rhoc) * (fabsf(h12 * s.h2) + 2.0f * fabsf(h13 * s.h3) + fabsf(h14 * s.h4) +
+                                                        fabsf(rhoc * (h15 * s.h5)));
     return (start == 1) ? -bb1 : bb1;
 }
 
 template <bool PIPE2 = true>
 __device__ __forceinline__ float delta_rayleigh(const float *wq, const int LS, const int S,
                                                 const int mmax, const float c, const float T,
-                                                const int start, float &phi)
+                                                const int start, float &phi, float *mag = nullptr, const bool want_mag = true)
 {
     // phi: vertical phase sum_i k d_i sqrt(c^2/v_i^2 - 1) over the layers (and wave types) that are oscillatory
     // at c -- the WKB mode counter the opt-in fast scan bounds between two coarse points (free: pm and qm are
@@ -546,7 +550,7 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int LS, c
         A = Bq;
     }
     // A holds layer mmax-1 here; the state is in the scale of the last layer stepped through
-    return ray_close(s, t, A, W_R(last), last >= 1 ? W_R(last - 1) : 0.0f, start);
+    return ray_close(s, t, A, W_R(last), last >= 1 ? W_R(last - 1) : 0.0f, start, mag, want_mag);
 }
 
 // The exact fallback kernel's Rayleigh secular function: DLTAR4 restated statement by statement (surfa.f:193-357),
@@ -554,8 +558,15 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int LS, c
 // overflows to inf, and every inf - inf turns NaN, exactly where the reference's does (which decides the "roots" the
 // reference returns next to the overflowed region).  Working stack of that kernel: a in the W_IA2 slot.
 // start = 1 -> dispersion (-bb1); 2 / 3 -> the two ellipticity passes (bb1), combined by the caller (surfa.f:360-363).
-__device__ __noinline__ float delta_rayleigh_ref(const float *wq, const int LS, const int S,
-                                                 const int mmax, const float c, const float t, const int start)
+// AINV: called on the PRODUCTION kernel's working stack, whose W_IA2 slot holds 1/a^2 (to 1 ulp) instead of a: a is taken
+// as 1/sqrt of it (IEEE) - the reference's arithmetic on a P velocity that may differ from its own in the last bit, which
+// moves the value ten times less than the production recursion's rounding does (the scan's ambiguity re-evaluation).
+// (The production kernel inlines the body: a call would cost its wavefronts a fourth of their registers - the calling
+// convention's - and with them the fourth wavefront per SIMD.)
+struct RefLyr { float a, b, rho, d; };
+// GET: m -> the working stack's values of layer m (called for m = 0 .. mmax - 1, once each, in order)
+template <class GET>
+__device__ __forceinline__ float delta_rayleigh_ref_gen(GET get, const int mmax, const float c, const float t, const int start)
 {
 #pragma clang fp contract(off)
     const float accur = 1.e-8f, accurs = 1.e-8f;
@@ -564,8 +575,10 @@ __device__ __noinline__ float delta_rayleigh_ref(const float *wq, const int LS, 
     float b1 = (start == 1) ? 1.0f : 0.0f, b2 = (start == 2) ? 1.0f : 0.0f, b3 = (start == 3) ? 1.0f : 0.0f,
           b4 = 0.0f, b5 = 0.0f;
     float ra = 0.0f, rb = 0.0f, g = 0.0f, g1 = 0.0f;
+    RefLyr yl{1.0f, 1.0f, 1.0f, 0.0f};
     for (int m = 0; m < mmax; ++m) {
-        const float pm_ = W_IA2(m), sm = W_B(m), rho = W_R(m), d = W_D(m);     // p(m), s(m), rho(m), d(m)
+        yl = get(m);
+        const float pm_ = yl.a, sm = yl.b, rho = yl.rho, d = yl.d;             // p(m), s(m), rho(m), d(m)
         const float arga = 1.0f - csq / (pm_ * pm_);
         ra = sqrtf(fabsf(arga));
         if (arga > 0.0f) ra = -ra;
@@ -628,8 +641,8 @@ __device__ __noinline__ float delta_rayleigh_ref(const float *wq, const int LS, 
         b1 = bb1; b2 = bb2; b3 = bb3; b4 = bb4; b5 = bb5;
     }
     // label 52: the half space (ra, rb, g, g1 of layer mmax from the last trip of the loop)
-    const float pp = W_IA2(mmax - 1), sss = W_B(mmax - 1) * W_B(mmax - 1), ppp = pp * pp;
-    const float rhp = W_R(mmax - 1) * pp;
+    const float pp = yl.a, sss = yl.b * yl.b, ppp = pp * pp;
+    const float rhp = yl.rho * pp;
     const float gra = g * ra, g1s = g1 * g1, rba = rb - 1.0f / ra;
     const float h11 = -2.0f * rb * sss / ppp + csq * g1s / ppp / gra;
     float h12 = rhp * pp;
@@ -639,6 +652,18 @@ __device__ __noinline__ float delta_rayleigh_ref(const float *wq, const int LS, 
     h12 = -1.0f / g / h12;
     const float bb1 = h11 * b1 + h12 * b2 + 2.0f * h13 * b3 + h14 * b4 + h15 * b5;
     return (start == 1) ? -bb1 : bb1;
+}
+template <bool AINV>
+__device__ __forceinline__ float delta_rayleigh_ref_body(const float *wq, const int LS, const int S,
+                                                         const int mmax, const float c, const float t, const int start)
+{
+    return delta_rayleigh_ref_gen([&](int m) { return RefLyr{AINV ? 1.0f / sqrtf(W_IA2(m)) : W_IA2(m), W_B(m), W_R(m), W_D(m)}; },
+                                  mmax, c, t, start);
+}
+__device__ __noinline__ float delta_rayleigh_ref(const float *wq, const int LS, const int S,
+                                                 const int mmax, const float c, const float t, const int start)
+{
+    return delta_rayleigh_ref_body<false>(wq, LS, S, mmax, c, t, start);
 }
 
 // Love: Thomson-Haskell 2-vector from the half space up, surfa.f:143-179 (production kernel; the reference's own
@@ -654,8 +679,9 @@ __device__ __noinline__ float delta_rayleigh_ref(const float *wq, const int LS, 
 template <bool CERT = false>
 __device__ __forceinline__ float delta_love(const float *wq, const int LS, const int S,
                                             const int mmax, const float c, const float T, float &phi, int &kc, bool &kunc,
-                                            const bool count = true)
+                                            const bool count = true, float *mag = nullptr)
 {
+    float lmag = 0.0f;                                     // |h z ut| + |cosq tt| of the last step (see ray_close's mag)
     kc = 0; kunc = !count;                                 // (count = false: no certificate from this trial)
     phi = 0.0f;                                            // see delta_rayleigh
     const float wvno = 6.2831853f * rcp_nr(c * T);
@@ -691,6 +717,7 @@ __device__ __forceinline__ float delta_love(const float *wq, const int LS, const
         phi -= (arg < 0.0f) ? 0.0f : q;
         const float eut = cosq * ut - yv * tt * ih;
         const float ett = h * z * ut + cosq * tt;
+        lmag = fabsf(h * z * ut) + fabsf(cosq * tt);
         if (CERT && count) {
             const bool flip = (tt < 0.0f) != (ett < 0.0f);
             if (arg < 0.0f) {
@@ -720,12 +747,13 @@ __device__ __forceinline__ float delta_love(const float *wq, const int LS, const
         m -= 2;
     }
     if (m == 0) step(A);
+    if (mag) *mag = lmag;
     return -tt;
 }
 
 // ... and its Love secular function: DLTAR1 statement by statement (surfa.f:143-179), same rules.
-__device__ __noinline__ float delta_love_ref(const float *wq, const int LS, const int S,
-                                             const int mmax, const float c, const float t)
+__device__ __forceinline__ float delta_love_ref_body(const float *wq, const int LS, const int S,
+                                                     const int mmax, const float c, const float t)
 {
 #pragma clang fp contract(off)
     const float wvno = 6.2831853f / (c * t);
@@ -757,6 +785,11 @@ __device__ __noinline__ float delta_love_ref(const float *wq, const int LS, cons
         ut = eut; tt = ett;
     }
     return -tt;
+}
+__device__ __noinline__ float delta_love_ref(const float *wq, const int LS, const int S,
+                                             const int mmax, const float c, const float t)
+{
+    return delta_love_ref_body(wq, LS, S, mmax, c, t);
 }
 
 // layer dropping for one trial velocity, surfa.f:94-105.  No early exit: every load is independent
@@ -913,6 +946,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     // NEVILL's state between two evaluations (c1, del1 = p0c, p0d; c2, del2 = cb, db; c3 = croot)
     int nv_nev = 1, nv_m = 1, nv_ic = 0;
     bool defer = false;                // !EXACT: this stack goes to the exact fallback kernel
+    bool ell_flag = false;             // in-kernel ellipticity of the period at hand: to be redone by the ellipticity kernel
 
     // (re)build the working stack for period k over the first nflat layers only -- the reference
     // refreshes just the layers inside the previous period's effective half space and leaves the
@@ -953,6 +987,23 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    // growth of the vertical phase between two trial velocities over the first mm - 1 layers of the working stack (see the
+    // bracket branch of the scan); every lane of the team calls it
+    auto bracket_phase = [&](float c1, float c2, int mm) -> float {
+        const float om = 6.2831853f * __builtin_amdgcn_rcpf(T);
+        const float i1 = __builtin_amdgcn_rcpf(c1 * c1), i2 = __builtin_amdgcn_rcpf(c2 * c2);
+        float sum = 0.0f;
+        for (int i = j; i < mm - 1; i += G) {
+            const float od = om * W_D(i);
+            const float ib2 = (KIND == 2) ? W_IB2(i) : W_IR(i) * W_R(i);       // 1/b^2 (0: liquid)
+            sum += od * (sqrt_hw(fmaxf(ib2 - i2, 0.0f)) - sqrt_hw(fmaxf(ib2 - i1, 0.0f)));
+            if (KIND == 2) { const float ia2 = W_IA2(i); sum += od * (sqrt_hw(fmaxf(ia2 - i2, 0.0f)) - sqrt_hw(fmaxf(ia2 - i1, 0.0f))); }
+        }
+#pragma unroll
+        for (int d = G >> 1; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+        return fabsf(sum);
     };
 
     // Rayleigh, production kernel: can a matrix ENTRY of the reference overflow fp32 in this period although the
@@ -1092,11 +1143,33 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             wtrip += mx; wlanelayers += sm; wlanes += __popcll(__ballot(eval));
         }
 #endif
+        float vmag = 0.0f;                                     // magnitude of the terms the value is the sum of (production recursion)
         if (eval) {
+#ifdef SD_AMBIG
+            const bool want_mag = true;
+#else
+            const bool want_mag = want_ratio && st == ST_ELLIP;   // (the in-kernel ellipticity passes' cancellation test)
+#endif
             if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, LS, S, mmj, cj, Tl, start)
-                                       : delta_rayleigh<(G != 2) && !FAST>(wl, LS, S, mmj, cj, Tl, start, phj);
-            else           val = EXACT ? delta_love_ref(wl, LS, S, mmj, cj, Tl) : delta_love<CERT>(wl, LS, S, mmj, cj, Tl, phj, kcj, kuncj, coarse);   // counts only where they are compared: coarse passes
+                                       : delta_rayleigh<(G != 2) && !FAST>(wl, LS, S, mmj, cj, Tl, start, phj, &vmag, want_mag);
+            else           val = EXACT ? delta_love_ref(wl, LS, S, mmj, cj, Tl) : delta_love<CERT>(wl, LS, S, mmj, cj, Tl, phj, kcj, kuncj, coarse, &vmag);   // counts only where they are compared: coarse passes
         }
+        // (-DSD_AMBIG builds only, see DESIGN.md.)  A scan trial whose value is the remainder of a cancellation - |value| below A.ambig of the terms it is the sum of -
+        // has a SIGN within the rounding of the production recursion, and the scan decides on signs (calcul.f:157-167): a
+        // flipped sign moves the bracket by one grid step onto a neighbouring root or past a pair of close roots (the zero
+        // pattern mismatches of the soaks, 2e-5 of random stacks).  Such a trial is evaluated again with the reference's own
+        // arithmetic (DLTAR4 / DLTAR1 statement by statement) and that value's sign is used.  Rare by construction (counted in
+        // A.amb_count); the wavefront's other lanes wait for it.
+#ifdef SD_AMBIG
+        if (!EXACT && eval && st == ST_SCAN && !ell_lane && A.ambig > 0.0f && fabsf(val) < A.ambig * vmag) {
+            val = (KIND == 2) ? delta_rayleigh_ref_body<true>(wl, LS, S, mmj, cj, Tl, 1) : delta_love_ref_body(wl, LS, S, mmj, cj, Tl);
+            if (A.amb_count) atomicAdd(A.amb_count, 1);
+        }
+#endif
+        // ... and the in-kernel ellipticity passes (two-lane teams) likewise: a closure that is the remainder of a cancellation
+        // marks the (stack, period) for the ellipticity kernel, which evaluates both passes with the reference's arithmetic
+        // on the replayed working stack (see there)
+        const bool ell_amb = !EXACT && want_ratio && eval && st == ST_ELLIP && A.ell_ambig > 0.0f && fabsf(val) < A.ell_ambig * vmag;
 #ifdef SD_WAVECLOCK
         wcyc_eval += __builtin_readcyclecounter() - we0;
 #endif
@@ -1279,7 +1352,16 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 p0ok = (e_pmm == e_mm);
                 passes = 0;
                 st = LOCK ? ST_WREF : ST_REFINE;
-                if (EXACT) {                                   // NEVILL's prologue, surfa.f:12-16
+                // EXACT: always NEVILL.  Production: NEVILL (statement by statement, from the scan's bracket) when the
+                // bracket may hold SEVERAL roots: consecutive modes are ~pi apart in the vertical phase (sum of omega d
+                // sqrt(1/v^2 - 1/c^2) over the oscillatory layers), so a bracket across which it grows by more than A.phimulti
+                // (1 rad; an ordinary bracket's growth is 1e-2) - thick soft layers at short periods, overtones 1e-3 km/s
+                // apart - may hold more than one, which of them NEVILL lands on depends on its evaluation sequence, and a
+                // team of a few lanes cannot see them: the subdivision's own test (`multi`: more than one sign change among
+                // the G points of the first refine pass) only sees roots further apart than its points.  r04 soak: 4e-3 of
+                // the soft-sediment family's Love stacks came back on another overtone (1 .. 15 % off) from teams of <= 8
+                // lanes.  The phase is summed by the team, once per bracket (a layer per lane and turn).
+                if (EXACT || bracket_phase(p0c, cb, mm_frozen) > A.phimulti) {   // NEVILL's prologue, surfa.f:12-16 (del1 is the scan's value, whatever layer dropping it was computed with - as in the reference)
                     nv_ic = 0; nv_nev = 1; nv_m = 1;
                     croot = (p0c + cb) / 2.0f;                 // c3, evaluated by the next pass
                     st = ST_NEVILL;
@@ -1390,7 +1472,16 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 // subdivide again: near osculating modes Delta(c) is strongly curved and only a tight
                 // bracket pins the root the reference finds.
                 const float w = cb - p0c, sx = tc - p0c;
-                const float f0 = p0d, f1 = db, f2 = td;
+                // The estimates below are ratios of PRODUCTS of function values, formed with v_rcp_f32 - which returns 0 for
+                // arguments beyond 2^126 and flushes results below 2^-126: with |Delta| ~ 1e19 .. 1e20 (water layer over soft
+                // sediments at periods of a few seconds) the denominators (f1 - f0)(f1 - f2) ~ 1e38 .. 1e40 turned BOTH
+                // three-point estimates into exactly 0, they "agreed", and the bracket's low end - a subdivision point up to
+                // 1e-3 km/s from the root - was returned as the root (r04 soak: 1e-5 of random stacks, all team sizes below 16
+                // lanes).  The values are brought to order one by a common power of two first (exact).
+                const float fm = fmaxf(fabsf(p0d), fabsf(db));
+                const int fex = (fm > 0.0f && fin(fm)) ? __builtin_amdgcn_frexp_expf(fm) : 0;
+                const float f0 = ldexpf(p0d, -fex), f1 = ldexpf(db, -fex), f2 = ldexpf(td, -fex);
+                ud = ldexpf(ud, -fex);
                 auto qt = [](float a, float bq) { return a * __builtin_amdgcn_rcpf(bq); };
                 float ts = qt(-f0 * w, f1 - f0);
                 float t = qt(w * (f0 * f2), (f1 - f0) * (f1 - f2)) + qt(sx * (f0 * f1), (f2 - f0) * (f2 - f1));
@@ -1443,6 +1534,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 }
             }
         } else if (st == ST_ELLIP) {
+            if ((__ballot(ell_amb) & tmask) != 0ull) ell_flag = true;
             if (G == 1) {
                 if (sub == 0) { r12 = val; sub = 1; }
                 else { r12 = 0.5f * val / r12; solved = true; }
@@ -1481,8 +1573,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             if (j == 0) {
                 A.c[(size_t)k * B + b] = croot;                // period-major: coalesced across teams
                 if (want_ratio && !ell_pend) A.ratio[(size_t)k * B + b] = r12;
-                if (A.hist) A.hist[(size_t)k * B + b] = EXACT ? -1 : (nflat_cur | (mm_frozen << 16));
+                if (A.hist) A.hist[(size_t)k * B + b] = EXACT ? -1 : (nflat_cur | (mm_frozen << 16) | (ell_flag ? 0x40000000 : 0));
             }
+            ell_flag = false;
             nsolved = ++k;
             if (INDEP || k >= P) { st = ST_DONE; }
             else {
@@ -1553,6 +1646,11 @@ __global__ __launch_bounds__(SD_PHASE_BLOCK) void surfdisp_phase_kernel(PhaseArg
 // history: layer i carries the values of the LAST period k' <= k whose rebuild covered it (k' falls monotonically as i
 // grows), with the same expressions the rebuild uses (layer_derive, rcp_nr), then steps both start vectors through
 // ray_step / ray_close - the root search's own functions.
+// r04: where the closure of either pass is the remainder of a cancellation (|value| below A.ell_ambig of its terms: soft
+// sediments at c < 0.5 km/s, where the production recursion's ellipticity was good to 3e-4 .. 3e-3 only and cost 1e-4 of the
+// group velocity) BOTH passes are evaluated again with the reference's own arithmetic (DLTAR4 statement by statement on the
+// replayed working stack) - the value calcul.f:195 itself forms.  only_flagged: the root search computed the ellipticities
+// itself (two-lane teams) and marked the (stack, period) pairs that need this (bit 30 of the history word).
 __global__ __launch_bounds__(256) void surfdisp_ellip_kernel(EllipArgs A)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1563,44 +1661,63 @@ __global__ __launch_bounds__(256) void surfdisp_ellip_kernel(EllipArgs A)
     if (n < 2 || k >= A.nsolved[b]) return;                 // (the finish kernel writes 0 for unsolved periods)
     const int hk = A.hist[idx];
     if (hk < 0) return;                                      // computed by the exact fallback kernel itself
-    const int mmf = hk >> 16;
+    if (A.only_flagged && !(hk & 0x40000000)) return;
+    const int mmf = (hk >> 16) & 0x3fff;
     const size_t fs = (size_t)A.Lmax * B;
     const float c = A.c[idx], T = A.per[k];
-    const RTrial t = ray_trial(c, T);
-    int kk = k;                                              // period whose rebuild last refreshed the layer at hand
-    int nflat = hk & 0xffff;
-    float lnT = logf(1.0f / T);
-    RState s2{}, s3{};
-    float phi = 0.0f, rho_prev = 0.0f;
-    RLyr y{};
-    float rho_i = 0.0f;
+    // the working stack as phase 1 left it, layer by layer (i = 0, 1, ... in order): the period whose rebuild last refreshed
+    // layer i, and that rebuild's extent
+    struct Replay { int kk, nflat; float lnT; };
+    const Replay r0{k, hk & 0xffff, logf(1.0f / T)};
+    auto layer = [&](int i, Replay &r) -> LayerV {
+        while (r.nflat <= i && r.kk > 0) {                   // an earlier rebuild: period 0 refreshed all n layers
+            --r.kk;
+            const int h = A.hist[(size_t)r.kk * B + b];
+            r.nflat = (h < 0) ? n : (h & 0xffff);
+            r.lnT = logf(1.0f / A.per[r.kk]);
+        }
+        return layer_derive(layer_load(A.mdl, fs, (size_t)i * B + b), r.lnT, i == r.nflat - 1);
+    };
     const int last = mmf - 1;
-    for (int i = 0; i <= last; ++i) {
-        while (nflat <= i && kk > 0) {                       // an earlier rebuild: period 0 refreshed all n layers
-            --kk;
-            const int h = A.hist[(size_t)kk * B + b];
-            nflat = (h < 0) ? n : (h & 0xffff);
-            lnT = logf(1.0f / A.per[kk]);
+    float v2 = 0.0f, v3 = 0.0f;
+    bool exact = A.only_flagged != 0;
+    if (!exact) {
+        const RTrial t = ray_trial(c, T);
+        Replay r = r0;
+        RState s2{}, s3{};
+        float phi = 0.0f, rho_prev = 0.0f;
+        RLyr y{};
+        float rho_i = 0.0f;
+        for (int i = 0; i <= last; ++i) {
+            const LayerV v = layer(i, r);
+            rho_prev = rho_i;
+            rho_i = v.rho;
+            y.sv = v.b; y.d = v.d;
+            y.ia2 = rcp_nr(v.a * v.a);
+            y.ib2 = (v.b > 0.0f) ? rcp_nr(v.b * v.b) : 0.0f;
+            y.rat = (i > 0) ? rho_prev * rcp_nr(rho_i) : 0.0f;
+            if (i == 0) {
+                const float irho0 = rcp_nr(rho_i);
+                s2 = ray_start(t, 2, irho0);
+                s3 = ray_start(t, 3, irho0);
+                if (last >= 1) { ray_step<true>(s2, t, y, 2, phi); ray_step<true>(s3, t, y, 3, phi); }
+            } else if (i < last) {
+                ray_step<false>(s2, t, y, 2, phi);
+                ray_step<false>(s3, t, y, 3, phi);
+            }
         }
-        const LayerV v = layer_derive(layer_load(A.mdl, fs, (size_t)i * B + b), lnT, i == nflat - 1);
-        rho_prev = rho_i;
-        rho_i = v.rho;
-        y.sv = v.b; y.d = v.d;
-        y.ia2 = rcp_nr(v.a * v.a);
-        y.ib2 = (v.b > 0.0f) ? rcp_nr(v.b * v.b) : 0.0f;
-        y.rat = (i > 0) ? rho_prev * rcp_nr(rho_i) : 0.0f;
-        if (i == 0) {
-            const float irho0 = rcp_nr(rho_i);
-            s2 = ray_start(t, 2, irho0);
-            s3 = ray_start(t, 3, irho0);
-            if (last >= 1) { ray_step<true>(s2, t, y, 2, phi); ray_step<true>(s3, t, y, 3, phi); }
-        } else if (i < last) {
-            ray_step<false>(s2, t, y, 2, phi);
-            ray_step<false>(s3, t, y, 3, phi);
-        }
+        const float rp = (last >= 1) ? rho_prev : 0.0f;
+        float m2 = 0.0f, m3 = 0.0f;
+        v2 = ray_close(s2, t, y, rho_i, rp, 2, &m2); v3 = ray_close(s3, t, y, rho_i, rp, 3, &m3);
+        exact = (A.ell_ambig > 0.0f) && (fabsf(v2) < A.ell_ambig * m2 || fabsf(v3) < A.ell_ambig * m3);
     }
-    const float rp = (last >= 1) ? rho_prev : 0.0f;
-    const float v2 = ray_close(s2, t, y, rho_i, rp, 2), v3 = ray_close(s3, t, y, rho_i, rp, 3);
+    if (exact) {
+        Replay r = r0;
+        v2 = delta_rayleigh_ref_gen([&](int m) { const LayerV v = layer(m, r); return RefLyr{v.a, v.b, v.rho, v.d}; }, mmf, c, T, 2);
+        r = r0;
+        v3 = delta_rayleigh_ref_gen([&](int m) { const LayerV v = layer(m, r); return RefLyr{v.a, v.b, v.rho, v.d}; }, mmf, c, T, 3);
+        if (A.amb_count) atomicAdd(A.amb_count + 1, 1);
+    }
     A.ratio[idx] = 0.5f * v3 / v2;                           // surfa.f:363
 }
 
@@ -1648,25 +1765,44 @@ SD_HD __forceinline__ Drop drop_group(const float *__restrict__ mdl, size_t fs, 
 }
 
 // Analytic partial derivatives of the phase velocity (the quantities REIGEN / LEIGEN form from their
-// energy integrals and never return: surfa.f:1130-1135, 1180-1183, 1204-1207 / 561-565, 584-585).
+// energy integrals and leave in COMMON /rar1/: surfa.f:1130-1135, 1180-1184, 1204-1207 / 509-512, 561-565, 581-583).
 // The eigenproblem is solved for the attenuation-dispersed, earth-flattened layer values; the
 // caller's derivatives are with respect to its own Vs, Vp, rho, so each layer carries the chain
 // factors of calcul.f:122-126 and flat1.f:44-62:
 //   b = b_ref (1 + qsq) f,  a = a_ref (1 + qsq 4/3 b_ref^2/a_ref^2) f,  rho = rho_ref r
-// this (stack, period)'s partials of layer i at b[i * stride] (a, r likewise; nullptrs when not wanted): stride 1 = the
-// caller's [B][P][Lmax] rows directly; stride P*B = the layer-major scratch of the kernels workspace, where the lanes of
-// a wavefront (consecutive stacks, one period) touch consecutive words - the rows are then written by
-// surfdisp_kern_transpose_kernel
-struct KernRow {
-    float *b, *a, *r;
-    size_t stride;
-    SD_HD float &B_(int i) const { return b[(size_t)i * stride]; }
-    SD_HD float &A_(int i) const { return a[(size_t)i * stride]; }
-    SD_HD float &R_(int i) const { return r[(size_t)i * stride]; }
+// (KOut::raw, SURFDISP_KERN_REFCOORD: unit chain factors - the partials with respect to the flattened, attenuated layer
+// values themselves, i.e. the reference's own numbers summed over a layer's sublayers; the water layer's share, which the
+// reference does not form, is left out: what tests/golden/ref_partials.npz pins.)
+//
+// Where they go (r04).  A unit = one (stack, period) = one lane.  Every layer's share is written ONCE, unscaled, as soon as
+// the sweep has it (a plain store: no zero fill, no read-modify-write; the share of the layer that also holds the half
+// space is kept in three registers until the half-space terms are known); the common factor 1 / (dL/dk) - known only after
+// the last layer - and the index of the deepest layer written go to two per-unit words, and the consumer applies them:
+//   * scratch route (kernels workspace): layer-major scratch [3][Lmax][P*B] - the lanes of a wavefront (consecutive stacks,
+//     one period) store consecutive words; surfdisp_kern_transpose_kernel reads it back through an LDS tile, multiplies by
+//     the unit's factor, writes zeros for layers below the unit's half space / unsolved units, and stores whole rows of the
+//     caller's [B][P][Lmax] arrays.  HBM traffic: scratch written once, read once, rows written once (r03: zero fill +
+//     accumulate + scale, each a read-modify-write of the scratch, + the transposition: 7.2 x the rows).
+//   * direct route (a workspace without the scratch): the same stores go to the caller's rows (stride 1) and the lane
+//     itself scales / zero-fills its rows at the end - the same products, so both routes agree bit for bit.
+struct KOut {
+    float *b;                 // this unit's entry of layer 0 in the dc/dVs array; nullptr: no partials
+    size_t stride;            // words between consecutive layers (uniform)
+    ptrdiff_t off_a, off_r;   // BYTE offsets of the dc/dVp and dc/drho entries from the dc/dVs entry (uniform; 0: not wanted)
+    int raw;                  // reference coordinates (see above)
+    SD_HD void put(int i, float vb, float va, float vr) const
+    {
+        float *q = b + (size_t)i * stride;
+        *q = vb;
+        if (off_a) *reinterpret_cast<float *>(reinterpret_cast<char *>(q) + off_a) = va;
+        if (off_r) *reinterpret_cast<float *>(reinterpret_cast<char *>(q) + off_r) = vr;
+    }
 };
+struct K3 { float b, a, r; };
 struct Chain { float dbdb, dadb, dada, rfac; };
-SD_HD __forceinline__ Chain chain_of(const LayerRaw &r, float lnT, bool is_halfspace)
+SD_HD __forceinline__ Chain chain_of(const LayerRaw &r, float lnT, bool is_halfspace, bool raw)
 {
+    if (raw) return Chain{1.0f, 0.0f, 1.0f, 1.0f};
     const float qsq = r.qs * lnT / PI_REF;
     const float qpq = qsq * 1.33333333f * (r.b_ref * r.b_ref) / (r.a_ref * r.a_ref);
     const float vfac = is_halfspace ? r.hsf : r.dif;
@@ -1677,22 +1813,34 @@ SD_HD __forceinline__ Chain chain_of(const LayerRaw &r, float lnT, bool is_halfs
     ch.rfac = is_halfspace ? r.hsr : r.qqq;
     return ch;
 }
-// add one (sub)layer group's share: the six integrals of surfa.f:1110-1121 -> dL/d(lambda, mu, rho)
-// -> dc/d(b, a, rho) of the flattened layer (still to be divided by dL/dk) -> the caller's layer
-SD_HD __forceinline__ void kern_add_rayleigh(const KernRow &ko, int jl, const Chain &ch, const LayerV &v,
-                                             float xlamb, float xmu, float c, float wvno, float wvnosq,
-                                             float omegsq, double dmmr, double dmmz, double drsz,
-                                             double dzsr, double smmz, double smmr)
+// One layer's share from its six energy integrals (surfa.f:1110-1121, summed over the layer's sublayers) -> dL/d(lambda,
+// mu, rho) (surfa.f:1130-1132) -> dc/d(b, a, rho) of the flattened layer, still to be divided by dL/dk (surfa.f:1133-1135)
+// -> the caller's layer.  Everything that depends on the layer alone - 2 rho b c/k and the chain factors - is folded into
+// four coefficients when the layer is entered (KC: the layer's raw values need not stay in registers across its RK4 steps).
+// fp32: the integrals are fp32 Boole sums; 1e-7 of their largest term is 1e-6 of a period's largest partial.
+struct KC { float b1, b2, a, r; };
+SD_HD __forceinline__ KC kern_coef(const LayerRaw &raw, const LayerV &v, float lnT, bool is_halfspace, float cw, bool rawc)
 {
-    const double dldl = -wvnosq * dmmr + 2.0 * wvno * drsz - smmz;
-    const double dldm = -wvnosq * (2.0 * dmmr + dmmz) - 2.0 * wvno * dzsr - (2.0 * smmz + smmr);
-    const double dldr = omegsq * (dmmr + dmmz);
-    const double db = 2.0 * v.rho * v.b * c * (dldm - 2.0 * dldl) / wvno;
-    const double da = 2.0 * v.rho * v.a * c * dldl / wvno;
-    const double dr = (c / wvno) * (dldr + xlamb * dldl / v.rho + xmu * dldm / v.rho);
-    ko.B_(jl) += (float)(db * ch.dbdb + da * ch.dadb);
-    if (ko.a) ko.A_(jl) += (float)(da * ch.dada);
-    if (ko.r) ko.R_(jl) += (float)(dr * ch.rfac);
+    const Chain ch = chain_of(raw, lnT, is_halfspace, rawc);
+    const float rc2 = 2.0f * v.rho * cw;                     // 2 rho c / k
+    return KC{rc2 * v.b * ch.dbdb, rc2 * v.a * ch.dadb, rc2 * v.a * ch.dada, cw * ch.rfac / v.rho};
+}
+// KR: the type the six sums are carried and combined in.  dc/drho is the difference of the kinetic and the two elastic
+// terms, which cancel to ~1e-3 of their size (equipartition): combined in fp32 it came out 6e-4 of a period's peak off
+// the reference's value (tests/golden/ref_partials.npz) - the reference carries them DOUBLE PRECISION (surfa.f:717-722).
+#ifndef SD_KERN_REAL
+#define SD_KERN_REAL double
+#endif
+typedef SD_KERN_REAL KR;
+SD_HD __forceinline__ K3 kern_layer_rayleigh(const KC &kc, float rho, float xlamb, float xmu, float wvno, float wvnosq,
+                                             float omegsq, KR dmmr, KR dmmz, KR drsz, KR dzsr, KR smmz, KR smmr)
+{
+    const KR two = 2, k2 = wvnosq, tk = 2.0f * wvno;
+    const KR dldl = -k2 * dmmr + tk * drsz - smmz;
+    const KR dldm = -k2 * (two * dmmr + dmmz) - tk * dzsr - (two * smmz + smmr);
+    const KR dldr = (KR)omegsq * (dmmr + dmmz);
+    return K3{(float)((KR)kc.b1 * (dldm - two * dldl) + (KR)kc.b2 * dldl), (float)((KR)kc.a * dldl),
+              (float)((KR)kc.r * ((KR)rho * dldr + (KR)xlamb * dldl + (KR)xmu * dldm))};
 }
 
 // ---- Rayleigh, surfa.f:714-1192 ---------------------------------------------------------------
@@ -1810,7 +1958,7 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
                                                const Drop dr, float wvno, float wvnosq, float omegsq,
                                                double y[4], double z[4], bool do_y,
                                                double xnorm, double bbn, RInt &acc,
-                                               const KernRow ko = KernRow{nullptr, nullptr, nullptr, 1}, float c = 0.0f)
+                                               const KOut ko = KOut{nullptr, 1, 0, 0, 0}, float cw = 0.0f, K3 *hold = nullptr)
 {
 #pragma clang fp contract(off)   // both sweeps must see identical coefficients
     LayerRaw nraw = layer_load(mdl, fs, (size_t)dr.hs_layer * B + b);
@@ -1821,10 +1969,15 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
         const int nreg = (jl == dr.hs_layer) ? dr.nreg_hs : nsub;
         if (nreg <= 0) continue;
         const LayerV v = layer_derive(raw, lnT, jl == n - 1);
-        if (v.b <= 0.0f) continue;                                   // water: surfa.f:930
+        if (v.b <= 0.0f) {                                           // water: surfa.f:930
+            if (MODE == 2 && KERN && jl > 0) ko.put(jl, 0.0f, 0.0f, 0.0f);   // (the top layer's entry: group_rayleigh)
+            continue;
+        }
         const float dsub = (ndiv > 1 && !(jl == 0 && water)) ? v.d / div : v.d;
         const float xmu = v.rho * v.b * v.b;                         // surfa.f:831-832
         const float xlamb = v.rho * (v.a * v.a - 2.0f * v.b * v.b);
+        KC kc{};
+        if (MODE == 2 && KERN) kc = kern_coef(raw, v, lnT, jl == n - 1, cw, ko.raw != 0);
         RCoef q;
         q.ddz = -dsub / (4.0f * 1.0f);
         q.a12 = 1.0f / (xlamb + 2.0f * xmu);
@@ -1857,9 +2010,16 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
         const float dz = dsub / 4.0f;
         const float l2m = xlamb + 2.0f * xmu;
         const float ixmu = q.a34, il2m = q.a12;       // 1/mu, 1/(lambda+2mu): already formed above
-        float f_mr[5], f_mz[5], f_rz[5], f_zr[5], f_sz[5], f_sr[5];
+        float f_mr[5], f_mz[5], f_rz[5], f_zr[5];
         constexpr bool kern = KERN;
-        double k_mr = 0.0, k_mz = 0.0, k_rz = 0.0, k_zr = 0.0, k_sz = 0.0, k_sr = 0.0;   // this layer's sums
+        KR k_mr = 0, k_mz = 0, k_rz = 0, k_zr = 0, k_sz = 0, k_sr = 0;   // this layer's sums
+#ifdef SD_KERN_BOOLE_INCR
+        // the two strain integrals only the partials need: Boole sums formed knot by knot (weights 7 32 12 32 7), the
+        // knot shared with the next sublayer kept - no five-entry arrays alive across the RK4 steps
+        float w_sz = 0.0f, w_sr = 0.0f, t_sz = 0.0f, t_sr = 0.0f;
+#else
+        float f_sz[5], f_sr[5];
+#endif
         const double ibb = 1.0 / bbn;
         auto knot = [&](int kk) {
             // fast path: z[] is the combined, normalised solution (xnorm*y + z)/bb itself;
@@ -1875,13 +2035,26 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
             const float duzdz = (atz + wvno * xlamb * aur) * il2m;
             f_mr[kk] = aur * aur; f_mz[kk] = auz * auz;
             f_rz[kk] = aur * duzdz; f_zr[kk] = auz * durdz;
-            if (kern) { f_sz[kk] = duzdz * duzdz; f_sr[kk] = durdz * durdz; }
+            if (kern) {
+#ifdef SD_KERN_BOOLE_INCR
+                t_sz = duzdz * duzdz; t_sr = durdz * durdz;
+                const float wk = (kk == 2) ? 12.0f : ((kk & 1) ? 32.0f : 7.0f);
+                w_sz = fmaf(wk, t_sz, w_sz); w_sr = fmaf(wk, t_sr, w_sr);
+#else
+                f_sz[kk] = duzdz * duzdz; f_sr[kk] = durdz * durdz;
+#endif
+            }
         };
         for (int s = 0; s < nreg; ++s) {
             // bottom knot: the top knot of the sublayer below when it belongs to the same layer
             if (s == 0) knot(4);
             else { f_mr[4] = f_mr[0]; f_mz[4] = f_mz[0]; f_rz[4] = f_rz[0]; f_zr[4] = f_zr[0];
-                   f_sz[4] = f_sz[0]; f_sr[4] = f_sr[0]; }
+#ifdef SD_KERN_BOOLE_INCR
+                   if (kern) { w_sz = 7.0f * t_sz; w_sr = 7.0f * t_sr; }
+#else
+                   if (kern) { f_sz[4] = f_sz[0]; f_sr[4] = f_sr[0]; }
+#endif
+            }
 #pragma unroll
             for (int kk = 3; kk >= 0; --kk) {
                 if (two_vec) prop_apply(P, y);
@@ -1894,7 +2067,11 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
             const float drsz = SD_BOOLE(f_rz), dzsr = SD_BOOLE(f_zr);
             if (kern) {
                 k_mr += dmmr; k_mz += dmmz; k_rz += drsz; k_zr += dzsr;
+#ifdef SD_KERN_BOOLE_INCR
+                k_sz += hq * w_sz; k_sr += hq * w_sr;
+#else
                 k_sz += SD_BOOLE(f_sz); k_sr += SD_BOOLE(f_sr);
+#endif
             }
 #undef SD_BOOLE
             // the sublayer's contributions in fp32 as in the reference (surfa.f:1126-1128); only the
@@ -1903,16 +2080,18 @@ SD_HD __forceinline__ void rayleigh_sweep(const float *__restrict__ mdl, size_t 
             acc.i1 += (double)(l2m * dmmr + xmu * dmmz);
             acc.i2 += (double)(xmu * dzsr - xlamb * drsz);
         }
-        if (kern)
-            kern_add_rayleigh(ko, jl, chain_of(raw, lnT, jl == n - 1), v, xlamb, xmu, c, wvno, wvnosq, omegsq,
-                              k_mr, k_mz, k_rz, k_zr, k_sz, k_sr);
+        if (kern) {
+            const K3 sh = kern_layer_rayleigh(kc, v.rho, xlamb, xmu, wvno, wvnosq, omegsq, k_mr, k_mz, k_rz, k_zr, k_sz, k_sr);
+            if (jl == dr.hs_layer) *hold = sh;                       // the half-space terms join it (group_rayleigh)
+            else ko.put(jl, sh.b, sh.a, sh.r);
+        }
     }
 }
 
 template <bool KERN = false>
 SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
                                 float T, float c, float ratio, double *dbg = nullptr,
-                                const KernRow ko = KernRow{nullptr, nullptr, nullptr, 1})
+                                const KOut ko = KOut{nullptr, 1, 0, 0, 0}, float *kscale = nullptr, int *khs = nullptr)
 {
 #pragma clang fp contract(off)
     const float lnT = logf(1.0f / T);
@@ -1931,6 +2110,10 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
     const float omegsq = omega * omega;
     RInt acc; acc.i0 = 0.0; acc.i1 = 0.0; acc.i2 = 0.0;
     float tzz = 0.0f;
+    const float cw = c / wvno;                                        // (KERN) c / k
+    K3 hold{0.0f, 0.0f, 0.0f};                                        // (KERN) share of the layer that holds the half space
+    if (KERN) { *kscale = 0.0f; *khs = dr.hs_layer; }                 // no factor yet: the consumer writes zeros
+    float wat_a = 0.0f, wat_r = 0.0f;                                 // (KERN) the water layer's own share
     if (wet) {                                                        // surfa.f:879-910
         const float d1 = top.d;
         const float xl1 = top.rho * (top.a * top.a - 2.0f * top.b * top.b);
@@ -1960,17 +2143,18 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
             acc.i1 = xl1 * fac2;
             acc.i2 = xl1 * fac3;
             tzz = -top.rho * omegsq * sinra_over / cosra;
-            if (KERN) {
+            if (KERN && !ko.raw) {
                 // the water layer's own partials (the reference skips liquid layers, surfa.f:1088): in a
                 // fluid the dilatation is tau_zz/lambda, so int theta^2 dz = k^2 (c/a)^4 int ur^2 dz
                 const LayerRaw wraw = layer_load(mdl, fs, (size_t)b);
-                const Chain ch = chain_of(wraw, lnT, false);
-                const double dldl = -(double)wvnosq * (ra * ra) * (ra * ra) * fac2;
-                const double dldr = (double)omegsq * (fac1 + fac2);
-                if (ko.a) ko.A_(0) += (float)(2.0 * top.rho * top.a * c * dldl / wvno * ch.dada);
-                if (ko.r) ko.R_(0) += (float)((c / wvno) * (dldr + (double)top.a * top.a * dldl) * ch.rfac);
+                const Chain ch = chain_of(wraw, lnT, false, false);
+                const float dldl = -wvnosq * (ra * ra) * (ra * ra) * fac2;
+                const float dldr = omegsq * (fac1 + fac2);
+                wat_a = 2.0f * top.rho * top.a * cw * dldl * ch.dada;
+                wat_r = cw * (dldr + top.a * top.a * dldl) * ch.rfac;
             }
         }
+        if (KERN) ko.put(0, 0.0f, wat_a, wat_r);                      // (the sweep skips liquid layers)
     }
     // half-space start vectors, surfa.f:913-926, 986-989
     const LayerV hsv = layer_at(mdl, fs, (size_t)dr.hs_layer * B + b, lnT, dr.hs_layer == n - 1);
@@ -2033,7 +2217,7 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
         for (int i = 0; i < 4; ++i) { z[i] = (xnorm * y0[i] + z0[i]) / bbn; y[i] = 0.0; }
         aur = (float)z[0]; auz = (float)z[1];
         rayleigh_sweep<2, KERN>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
-                                y, z, false, xnorm, bbn, acc, ko, c);
+                                y, z, false, xnorm, bbn, acc, ko, cw, &hold);
     } else {
         // Robust path (thick structure / short period: the solutions grow by up to ~1e27 and the
         // rounding noise excited on the way up is far larger than the answer).  The reference stays
@@ -2047,7 +2231,7 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
         aur = (float)((xnorm * y0[0] + z0[0]) / bbn);
         auz = (float)((xnorm * y0[1] + z0[1]) / bbn);
         rayleigh_sweep<2, KERN>(mdl, fs, B, b, n, lnT, ndiv, water, div, dr, wvno, wvnosq, omegsq,
-                                y, z, true, xnorm, bbn, acc, ko, c);
+                                y, z, true, xnorm, bbn, acc, ko, cw, &hold);
     }
     if (wet && !any_solid) { aur = ratio; auz = 1.0f; }              // label 77777, surfa.f:1140-1144
     {   // label 7002, surfa.f:1145-1186
@@ -2067,31 +2251,25 @@ SD_HD float group_rayleigh(const float *__restrict__ mdl, size_t fs, int B, int 
         acc.i0 += hsv.rho * (dmmr + dmmz);
         acc.i1 += (xlamb + 2.0f * xmu) * dmmr + xmu * dmmz;
         acc.i2 += xmu * dzsr - xlamb * drsz;
-        if (KERN) {                                                   // surfa.f:1163-1164, 1178-1183
-            const double smmz = ra * a3 * a3 / 2.0f + 2.0f * ra * rb * a3 * a4 / (ra + rb) + rb * a4 * a4 / 2.0f;
-            const double smmr = ra * a1 * a1 / 2.0f + 2.0f * ra * rb * a1 * a2 / (ra + rb) + rb * a2 * a2 / 2.0f;
+        if (KERN) {                                                   // surfa.f:1163-1164, 1178-1184
+            const float smmz = ra * a3 * a3 / 2.0f + 2.0f * ra * rb * a3 * a4 / (ra + rb) + rb * a4 * a4 / 2.0f;
+            const float smmr = ra * a1 * a1 / 2.0f + 2.0f * ra * rb * a1 * a2 / (ra + rb) + rb * a2 * a2 / 2.0f;
             const LayerRaw hraw = layer_load(mdl, fs, (size_t)dr.hs_layer * B + b);
-            kern_add_rayleigh(ko, dr.hs_layer, chain_of(hraw, lnT, dr.hs_layer == n - 1), hsv, xlamb, xmu, c,
-                              wvno, wvnosq, omegsq, dmmr, dmmz, drsz, dzsr, smmz, smmr);
+            const K3 sh = kern_layer_rayleigh(kern_coef(hraw, hsv, lnT, dr.hs_layer == n - 1, cw, ko.raw != 0), hsv.rho, xlamb, xmu,
+                                              wvno, wvnosq, omegsq, (KR)dmmr, (KR)dmmz, (KR)drsz, (KR)dzsr, (KR)smmz, (KR)smmr);
+            ko.put(dr.hs_layer, hold.b + sh.b, hold.a + sh.a, hold.r + sh.r);
         }
     }
     if (dbg) { dbg[10] = acc.i0; dbg[11] = acc.i1; dbg[15] = acc.i2; }
     const float s0 = (float)acc.i0, s1 = (float)acc.i1, s2 = (float)acc.i2;
-    if (KERN) {                                                       // surfa.f:1203-1207
-        const float idldk = 1.0f / (-2.0f * (wvno * s1 + s2));
-        for (int i = 0; i <= dr.hs_layer; ++i) {
-            ko.B_(i) *= idldk;
-            if (ko.a) ko.A_(i) *= idldk;
-            if (ko.r) ko.R_(i) *= idldk;
-        }
-    }
+    if (KERN) *kscale = 1.0f / (-2.0f * (wvno * s1 + s2));           // 1 / (dL/dk), surfa.f:1203-1207: applied by the consumer
     return (wvno * s1 + s2) / (omega * s0);                           // surfa.f:1186
 }
 
 // ---- Love, surfa.f:374-606 (all fp32, as the reference) --------------------------------------
 template <bool KERN = false>
 SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, int n,
-                            float T, float c, const KernRow ko = KernRow{nullptr, nullptr, nullptr, 1})
+                            float T, float c, const KOut ko = KOut{nullptr, 1, 0, 0, 0}, float *kscale = nullptr, int *khs = nullptr)
 {
     const float lnT = logf(1.0f / T);
     int ndiv = 5;
@@ -2107,18 +2285,19 @@ SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, i
     constexpr bool kern = KERN;
     const float wvnosq = wvno * wvno;
     const float omega = 6.2831853f / T, omegsq = omega * omega;
-    // one layer's share of dc/db, dc/drho (surfa.f:561-565), still to be divided by dL/dk
-    auto kern_add = [&](int jl, const LayerRaw &raw, const LayerV &v, float dm, float sm) {
-        const Chain ch = chain_of(raw, lnT, jl == n - 1);
+    const float cw = c / wvno;
+    // one layer's share of dc/db, dc/drho (surfa.f:509-512, 561-565), still to be divided by dL/dk
+    auto kern_layer = [&](int jl, const LayerRaw &raw, const LayerV &v, float dm, float sm) -> K3 {
+        const Chain ch = chain_of(raw, lnT, jl == n - 1, ko.raw != 0);
         const float dldm = -(wvnosq * dm + sm);
         const float dldr = omegsq * dm;
-        ko.B_(jl) += 2.0f * v.rho * v.b * c * dldm / wvno * ch.dbdb;
-        if (ko.r) ko.R_(jl) += (c / wvno) * (dldr + v.b * v.b * dldm) * ch.rfac;
+        return K3{2.0f * v.rho * v.b * cw * dldm * ch.dbdb, 0.0f, cw * (dldr + v.b * v.b * dldm) * ch.rfac};
     };
+    if (kern) { *kscale = 0.0f; *khs = dr.hs_layer; }
     float ut0 = 1.0f;
     for (int attempt = 0; attempt < 16; ++attempt) {
         float ut = ut0;
-        if (kern) for (int i = 0; i <= dr.hs_layer; ++i) { ko.B_(i) = 0.0f; if (ko.r) ko.R_(i) = 0.0f; }
+        K3 hold{0.0f, 0.0f, 0.0f};                                    // (KERN) share of the layer that holds the half space
         const float covb = c / hsv.b;
         const float hh = hsv.rho * hsv.b * hsv.b;
         const float rbh = wvno * sqrtf(fabsf(covb * covb - 1.0f));
@@ -2128,9 +2307,9 @@ SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, i
         float sumi1 = hh * dm0;
         bool overflow = false;
         LayerRaw nraw = layer_load(mdl, fs, (size_t)dr.hs_layer * B + b);
-        // the half space itself: u = ut0 exp(-rb z), so int u^2 = ut0^2/(2 rb), int (du/dz)^2 = ut0^2 rb/2
-        // (the reference leaves its half-space entry at zero, surfa.f:578-579; the share is real)
-        if (kern && rbh > 0.0f) kern_add(dr.hs_layer, nraw, hsv, dm0, 0.5f * rbh);
+        // the half space itself (surfa.f:502-512): int u^2 = 1/(2 rb), int (du/dz)^2 = rb/2 - like the reference's sumi0 /
+        // sumi1 start values not scaled with ut0^2
+        if (kern && rbh > 0.0f) hold = kern_layer(dr.hs_layer, nraw, hsv, dm0, 0.5f * rbh);
         for (int jl = dr.hs_layer; jl >= 0 && !overflow; --jl) {
             const LayerRaw raw = nraw;
             if (jl > 0) nraw = layer_load(mdl, fs, (size_t)(jl - 1) * B + b);
@@ -2140,6 +2319,7 @@ SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, i
             const LayerV v = layer_derive(raw, lnT, jl == n - 1);
             if (v.b == 0.0f) {                                        // surfa.f:524 (still tests |ut|)
                 if (fabsf(ut) > 1.0e10f) overflow = true;
+                if (kern && jl != dr.hs_layer) ko.put(jl, 0.0f, 0.0f, 0.0f);
                 continue;
             }
             const float dsub = (ndiv > 1 && !(jl == 0 && water)) ? v.d / div : v.d;
@@ -2188,12 +2368,16 @@ SD_HD float group_love(const float *__restrict__ mdl, size_t fs, int B, int b, i
                     k_sm += (dz / 22.5f) * (7.0f * (smm[0] + smm[4]) + 32.0f * (smm[1] + smm[3]) + 12.0f * smm[2]);
                 }
             }
-            if (kern && !overflow) kern_add(jl, raw, v, k_dm, k_sm);
+            if (kern && !overflow) {
+                const K3 sh = kern_layer(jl, raw, v, k_dm, k_sm);
+                if (jl == dr.hs_layer) { hold.b += sh.b; hold.r += sh.r; }
+                else ko.put(jl, sh.b, 0.0f, sh.r);
+            }
         }
         if (overflow) { ut0 = ut0 / 1.0e5f; continue; }
         if (kern) {                                                   // surfa.f:581-585
-            const float idldk = 1.0f / (-2.0f * wvno * sumi1);
-            for (int i = 0; i <= dr.hs_layer; ++i) { ko.B_(i) *= idldk; if (ko.r) ko.R_(i) *= idldk; }
+            ko.put(dr.hs_layer, hold.b, 0.0f, hold.r);
+            *kscale = 1.0f / (-2.0f * wvno * sumi1);                  // 1 / (dL/dk): applied by the consumer
         }
         sumi0 = sumi0 / (ut * ut);
         sumi1 = sumi1 / (ut * ut);
@@ -2208,7 +2392,10 @@ template <int KIND, bool KERN>
 #ifndef SD_GROUP_WAVES
 #define SD_GROUP_WAVES 3
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KERN ? 1 : SD_GROUP_WAVES, 8)))
+#ifndef SD_KERN_WAVES
+#define SD_KERN_WAVES 1
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KERN ? SD_KERN_WAVES : SD_GROUP_WAVES, 8)))
 void surfdisp_group_kernel(GroupArgs A)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2217,37 +2404,51 @@ void surfdisp_group_kernel(GroupArgs A)
     const int b = (int)(idx % B), k = (int)(idx / B);       // a wavefront = 64 stacks, one period
     const size_t o = idx;                                   // period-major [P][B]: coalesced
     const int n = A.nl[b];
-    KernRow ko{nullptr, nullptr, nullptr, 1};
-    if (KERN) {                                             // this unit's rows, zero-filled
-        float *ka_row;
+    KOut ko{nullptr, 1, 0, 0, 0};
+    float *ra_ = nullptr, *rr_ = nullptr;                   // direct route: this unit's dc/dVp, dc/drho rows
+    if (KERN) {
+        ko.raw = A.kraw;
         if (A.kscr) {                                       // layer-major scratch [3][Lmax][P][B]: coalesced
             const size_t arr = (size_t)A.Lmax * P * B;
             ko.stride = (size_t)P * B;
             ko.b = A.kscr + idx;
-            ka_row = A.ka ? A.kscr + arr + idx : nullptr;
-            ko.r = A.kr ? A.kscr + 2 * arr + idx : nullptr;
+            ko.off_a = (KIND == 2 && A.ka) ? (ptrdiff_t)(arr * sizeof(float)) : 0;
+            ko.off_r = A.kr ? (ptrdiff_t)(2 * arr * sizeof(float)) : 0;
         } else {                                            // the caller's [B][P][Lmax] rows (small workspace)
             const size_t ro = ((size_t)b * P + k) * A.Lmax;
             ko.stride = 1;
             ko.b = A.kb + ro;
-            ka_row = A.ka ? A.ka + ro : nullptr;
-            ko.r = A.kr ? A.kr + ro : nullptr;
-        }
-        ko.a = (KIND == 2) ? ka_row : nullptr;              // Love has no dc/dVp: its rows stay zero
-        for (int i = 0; i < A.Lmax; ++i) {
-            ko.B_(i) = 0.0f;
-            if (ka_row) ka_row[(size_t)i * ko.stride] = 0.0f;
-            if (ko.r) ko.R_(i) = 0.0f;
+            ra_ = A.ka ? A.ka + ro : nullptr;
+            rr_ = A.kr ? A.kr + ro : nullptr;
+            // (uniform byte distances between the caller's arrays; Love has no dc/dVp: its rows are zero-filled below)
+            ko.off_a = (KIND == 2 && A.ka) ? (ptrdiff_t)(reinterpret_cast<const char *>(A.ka) - reinterpret_cast<const char *>(A.kb)) : 0;
+            ko.off_r = A.kr ? (ptrdiff_t)(reinterpret_cast<const char *>(A.kr) - reinterpret_cast<const char *>(A.kb)) : 0;
         }
     }
-    if (n < 2 || k >= A.nsolved[b]) { A.u[o] = 0.0f; return; }
-    const size_t fs = (size_t)A.Lmax * B;
-    const float T = A.per[k];
-    const float c = A.c[o];
-    float ugr;
-    if (KIND == 2) ugr = group_rayleigh<KERN>(A.mdl, fs, B, b, n, T, c, A.ratio[(size_t)k * B + b],
-                                              A.dbg ? A.dbg + 16 * o : nullptr, ko);
-    else           ugr = group_love<KERN>(A.mdl, fs, B, b, n, T, c, ko);
+    float kscale = 0.0f;
+    int khs = -1;
+    float ugr = 0.0f;
+    if (n >= 2 && k < A.nsolved[b]) {
+        const size_t fs = (size_t)A.Lmax * B;
+        const float T = A.per[k];
+        const float c = A.c[o];
+        if (KIND == 2) ugr = group_rayleigh<KERN>(A.mdl, fs, B, b, n, T, c, A.ratio[(size_t)k * B + b],
+                                                  A.dbg ? A.dbg + 16 * o : nullptr, ko, &kscale, &khs);
+        else           ugr = group_love<KERN>(A.mdl, fs, B, b, n, T, c, ko, &kscale, &khs);
+    }
+    if (KERN) {
+        if (!(fabsf(kscale) <= 3.0e38f)) kscale = 0.0f;     // (no finite factor: zeros, as for an unsolved unit)
+        if (A.kscr) { A.kscale[o] = kscale; A.khs[o] = (kscale != 0.0f) ? khs : -1; }
+        else {
+            // direct route: the lane finishes its own rows - the products the transposition kernel forms on the scratch route
+            const int top = (kscale != 0.0f) ? khs : -1;
+            for (int i = 0; i < A.Lmax; ++i) {
+                ko.b[i] = (i <= top) ? ko.b[i] * kscale : 0.0f;
+                if (ra_) ra_[i] = (KIND == 2 && i <= top) ? ra_[i] * kscale : 0.0f;
+                if (rr_) rr_[i] = (i <= top) ? rr_[i] * kscale : 0.0f;
+            }
+        }
+    }
     A.u[o] = ugr;
 }
 
@@ -2290,24 +2491,30 @@ __global__ __launch_bounds__(256) void surfdisp_finish_kernel(FinishArgs A)
     }
 }
 
-// K2b: the analytic partials from the layer-major scratch [Lmax][P*B] (unit index u = k*B + b) to the caller's
+// K2b: the analytic partials from the layer-major scratch [3][Lmax][P*B] (unit index u = k*B + b) to the caller's
 // [B][P][Lmax] rows, 64 units x 64 layers per workgroup through an LDS tile: reads run along the units, writes along
-// the layers.
-__global__ __launch_bounds__(256) void surfdisp_kern_transpose_kernel(const float *__restrict__ scr, float *__restrict__ out,
-                                                                      int B, int P, int Lmax)
+// the layers.  Applies the unit's factor 1 / (dL/dk) and writes zeros below the unit's deepest layer (entries the
+// group-velocity kernel never wrote are not read).  blockIdx.z: 0 dc/dVs, 1 dc/dVp, 2 dc/drho.
+__global__ __launch_bounds__(256) void surfdisp_kern_transpose_kernel(KernTransposeArgs A)
 {
     __shared__ float tile[64][65];
+    const int B = A.B, P = A.P, Lmax = A.Lmax;
+    float *__restrict__ out = (blockIdx.z == 0) ? A.kb : ((blockIdx.z == 1) ? A.ka : A.kr);
+    if (!out) return;                                        // (block-uniform)
+    const float *__restrict__ scr = A.kscr + (size_t)blockIdx.z * Lmax * P * B;
+    const bool zero_only = (blockIdx.z == 1) && (A.kind != 2);   // Love has no dc/dVp
     const int nbb = (B + 63) / 64;
     const int k = blockIdx.x / nbb, b0 = (blockIdx.x % nbb) * 64, i0 = blockIdx.y * 64;
     const size_t PB = (size_t)P * B;
-    for (int t = threadIdx.x; t < 64 * 64; t += 256) {
-        const int il = t / 64, bl = t % 64;
-        if (i0 + il < Lmax && b0 + bl < B) tile[il][bl] = scr[(size_t)(i0 + il) * PB + (size_t)k * B + b0 + bl];
-    }
+    const int bl = threadIdx.x % 64;
+    float sc = 0.0f; int hs = -1;
+    if (b0 + bl < B && !zero_only) { sc = A.kscale[(size_t)k * B + b0 + bl]; hs = A.khs[(size_t)k * B + b0 + bl]; }
+    for (int il = threadIdx.x / 64; il < 64; il += 4)
+        tile[il][bl] = (i0 + il <= hs) ? scr[(size_t)(i0 + il) * PB + (size_t)k * B + b0 + bl] * sc : 0.0f;
     __syncthreads();
     for (int t = threadIdx.x; t < 64 * 64; t += 256) {
-        const int bl = t / 64, il = t % 64;
-        if (i0 + il < Lmax && b0 + bl < B) out[((size_t)(b0 + bl) * P + k) * Lmax + i0 + il] = tile[il][bl];
+        const int bq = t / 64, il = t % 64;
+        if (i0 + il < Lmax && b0 + bq < B) out[((size_t)(b0 + bq) * P + k) * Lmax + i0 + il] = tile[il][bq];
     }
 }
 
@@ -2431,10 +2638,10 @@ hipError_t launch_phase(hipStream_t s, int kind, int G, bool independent, const 
     return kind == 2 ? launch_phase_k<2, false>(s, a, G) : launch_phase_k<1, false>(s, a, G);
 }
 
-hipError_t launch_kern_transpose(hipStream_t s, const float *scr, float *out, int B, int P, int Lmax)
+hipError_t launch_kern_transpose(hipStream_t s, const KernTransposeArgs &a)
 {
-    const dim3 grid((unsigned)(P * ((B + 63) / 64)), (unsigned)((Lmax + 63) / 64));
-    hipLaunchKernelGGL(surfdisp_kern_transpose_kernel, grid, dim3(256), 0, s, scr, out, B, P, Lmax);
+    const dim3 grid((unsigned)(a.P * ((a.B + 63) / 64)), (unsigned)((a.Lmax + 63) / 64), 3u);
+    hipLaunchKernelGGL(surfdisp_kern_transpose_kernel, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

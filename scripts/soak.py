@@ -109,6 +109,77 @@ if off["cat"]:
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"soak_offenders_{TAG}.npz"),
                         **{k: np.asarray(v) for k, v in off.items()})
+# ---- why: every saved offender against the oracle's conditioning and against the reference's own two builds (the criterion of
+# tests/golden/u_exceptions*.json): a group velocity off by > 1e-4 is EXPLAINED when the entry is ill conditioned (the oracle's
+# U moves by > 1e-4 for a 2e-6 change of c), when the reference's FMA and non-FMA builds disagree there by > 2e-5 or one of them
+# returns NaN, or in the overflow regime (NaN on either side); a phase velocity off by > 1e-4 only when the reference's two builds
+# disagree by that much themselves
+def classify():
+    from oracle import refso
+    DC = 2e-6
+    have_ref = os.path.exists(refso._SO) and os.path.exists(refso._SO.replace("_ref.so", "_ref_fma.so"))
+    libs = [refso._SO, refso._SO.replace("_ref.so", "_ref_fma.so")]
+    counts = {}
+    unexpl = []
+    for q in range(min(len(off["cat"]), int(os.environ.get("SOAK_CLASSIFY", "2500")))):
+        cat = off["cat"][q]; n = off["nlay"][q]; P = off["P"][q]; kind = off["kind"][q]
+        m = np.ascontiguousarray(off["model"][q][:, :n]); per = off["per"][q][:P].copy()
+        c, co, u, uo = off["c"][q][:P], off["co"][q][:P], off["u"][q][:P], off["uo"][q][:P]
+        two = None
+        if have_ref:
+            two = []
+            for so in libs:
+                refso._SO = so; refso._lib = None
+                r = refso.fast_surf(n, kind, m[0], m[1], m[2], m[3], m[4], per, P)
+                two.append((r[2][:P], r[0][:P]) if kind == 2 else (r[3][:P], r[1][:P]))
+            refso._SO = libs[0]; refso._lib = None
+        # the oracle under "equally valid" fp32 evaluations of the reference's own formulas (oracle/surfdisp_oracle.c, g_variant:
+        # exponentials through exp2f, flattening factors from double-precision log / pow): does one of them return what the
+        # HIP path returned?  Then the result is decided by the rounding of the reference's libm, not by its formulas
+        var = []
+        for v in (1, 2, 3):
+            cport.lib().surfdisp_oracle_set_variant(v)
+            cv, uv, sv = cport.forward_batch(m[None], per, kind)
+            var.append((cv[0], uv[0]))
+        cport.lib().surfdisp_oracle_set_variant(0)
+        k = 0
+        with np.errstate(all="ignore"):
+            if cat == 0:
+                why = "zero pattern: UNEXPLAINED"
+                if two and not np.array_equal(two[0][0] > 0, two[1][0] > 0): why = "zero pattern: the reference's builds differ too"
+                elif any(np.array_equal(cv > 0, c > 0) for cv, uv in var): why = "zero pattern: as the oracle's with another rounding of exp / flattening"
+            elif cat == 1:
+                bad = np.abs(c / co - 1) > 1e-4
+                k = int(np.nanargmax(np.abs(c / co - 1)))
+                sp = abs(two[1][0][k] / two[0][0][k] - 1) if two and two[0][0][k] > 0 else 0.0
+                why = "c: UNEXPLAINED"
+                if sp > 1e-4: why = "c: the reference's builds disagree"
+                elif any((np.abs(c[bad] / cv[bad] - 1) < 2e-5).all() for cv, uv in var if (cv[bad] > 0).all()):
+                    why = "c: as the oracle's with another rounding of exp / flattening"
+            else:
+                e = np.nan_to_num(np.abs(u / uo - 1), nan=9.0)
+                e = np.where(~np.isfinite(uo) & ~np.isfinite(u), 0.0, e)
+                k = int(np.argmax(e))
+                if not (np.isfinite(uo[k]) and np.isfinite(u[k])):
+                    why = "U: overflow regime (NaN on one side)"
+                else:
+                    _, up = cport.group_at(m[None], per, kind, (co * np.float32(1 + DC))[None])
+                    _, um = cport.group_at(m[None], per, kind, (co * np.float32(1 - DC))[None])
+                    cond = max(abs(float(up[0][k]) - uo[k]), abs(float(um[0][k]) - uo[k])) / abs(uo[k])
+                    sp = abs(two[1][1][k] / two[0][1][k] - 1) if two else 0.0
+                    if not np.isfinite(cond) or cond > 1e-4: why = "U: ill conditioned (|dlnU/dlnc| x 2e-6 > 1e-4)"
+                    elif not np.isfinite(sp) or sp > 2e-5: why = "U: the reference's builds disagree"
+                    elif any(abs(u[k] / uv[k] - 1) < 5e-5 for cv, uv in var if uv[k] != 0): why = "U: as the oracle's with another rounding of exp / flattening"
+                    else: why = "U: UNEXPLAINED"
+        counts[why] = counts.get(why, 0) + 1
+        if "UNEXPLAINED" in why and len(unexpl) < 12:
+            unexpl.append((q, kind, off["team"][q], n, float(per[k]), float(c[k]), float(co[k]), float(u[k]), float(uo[k])))
+    print("soak offenders by cause (of the first", min(len(off["cat"]), int(os.environ.get("SOAK_CLASSIFY", "2500"))), "saved;",
+          "reference builds " + ("available" if have_ref else "NOT available") + "):")
+    for kq, v in sorted(counts.items(), key=lambda x: -x[1]): print(f"    {v:6d}  {kq}")
+    for t in unexpl: print("    unexplained: saved #%d kind=%d team=%d L=%d T=%.4f  c %.6f (oracle %.6f)  U %.6f (oracle %.6f)" % t)
+if off["cat"]:
+    classify()
 print(f"soak stacks with the reference's zero pattern but a phase velocity off by > 1e-4: {nbigc} ({nbigc / max(nstack, 1):.2e}); "
       f"with every phase velocity within 1e-4 but a group velocity off by > 1e-4: {nbigu} ({nbigu / max(nstack, 1):.2e}); "
       f"offending stacks saved: {len(off['cat'])}")

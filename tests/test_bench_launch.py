@@ -10,13 +10,22 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(n, extra_env=None):
+def _run(n, extra_env=None, extra_args=()):
     env = dict(os.environ, BENCH_REHEARSAL="cpu")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env.update(extra_env or {})
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", "launchcheck"],
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", "launchcheck", *extra_args],
                           env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_strong_scaling_flag_deals_one_grid_to_the_ranks():
+    """--total-points: the SAME grid for every rank count, contiguous blocks, every point owned once (the blocks the grid leg
+    would run; the leg itself needs a GPU: test_strong_scaling_grid_leg_on_one_gpu)."""
+    r = _run(2, extra_args=("--total-points", "4097"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert [x["points"] for x in d["ranks"]] == [[0, 2049], [2049, 4097]]
 
 
 def test_self_launch_two_ranks():
@@ -66,3 +75,23 @@ def test_two_rank_rehearsal_on_one_gpu_goes_through_the_launcher():
     assert d["value"] > 0 and abs(d["value"] - 2 * 512 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
     assert d["ms_per_step_max_over_ranks"] >= d["ms_per_step"] * 0.999
     assert d["roofline"]["live_kernel_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_strong_scaling_grid_leg_on_one_gpu():
+    """`bench.py --workload grid --total-points N`: one grid whatever the rank count - on one GPU all N points, as two
+    rehearsal ranks N/2 each; scaling "strong", value = Metropolis steps/s of the whole grid."""
+    env = dict(os.environ, BENCH_GRID_CHAINS="8")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = {}
+    for n in (1, 2):
+        e = dict(env, BENCH_REHEARSAL="1") if n > 1 else env
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", "grid", "--total-points", "128",
+                            "--steps", "3", "--warmup", "1"], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out[n] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    for n, d in out.items():
+        assert d["scaling"] == "strong" and d["n_gpus"] == n and d["config"]["total_points"] == 128
+        assert d["config"]["points_per_gpu"] == 128 // n and d["config"]["chains_per_gpu"] == 128 // n * 8
+        assert abs(d["value"] - 128 * 8 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6

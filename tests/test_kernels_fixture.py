@@ -214,3 +214,55 @@ def test_partials_through_the_scratch_equal_the_direct_route(kind):
         if a is not None:
             assert torch.equal(a, b)
     assert float(big[3].abs().max()) > 0.0
+
+
+# ---- the analytic partials against the reference's OWN numbers (COMMON /rar1/, tests/golden/make_golden_partials.py)
+PART = np.load(os.path.join(HERE, "golden", "ref_partials.npz"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [str(n) for n in PART["names"]])
+@pytest.mark.parametrize("w,kind", [("R", 2), ("L", 1)])
+def test_analytic_kernels_vs_reference_common_block(name, w, kind):
+    """dc/d(b, a, rho) of every layer in the reference's coordinates (SURFDISP_KERN_REFCOORD: the flattened, attenuated
+    layer values, no chain factors) against what REIGEN / LEIGEN themselves leave in COMMON /rar1/ (surfa.f:1133-1135,
+    1182-1184, 1204-1207; Love 511-512, 564-565, 582-583), summed over each layer's sublayers.  The fixture holds
+    one-period calls (the block is overwritten at every period) = SURFDISP_INDEPENDENT's start rule.  Bar: 1e-4 of the
+    period's largest entry (measured <= 3e-5), both routes (scratch + transposition kernel, direct rows)."""
+    import torch
+    from oracle import cport
+    from pysurfinv_amd import _lib, forward
+    m = np.ascontiguousarray(PART[f"{name}_model"][None], np.float32)
+    L = m.shape[2]
+    per = PART["periods"].astype(np.float32)
+    blk, meta = PART[f"{name}_{w}_rar1"], PART[f"{name}_{w}_meta"]
+    plan = forward.BatchPlan(1, L, per.size)
+    worst = 0.0
+    for small in (False, True):
+        c, u, st, kb, ka, kr = plan.run_kernels(torch.from_numpy(m).cuda(), torch.from_numpy(per).cuda(),
+                                                kind=kind | _lib.INDEPENDENT | _lib.KERN_REFCOORD, small_workspace=small)
+        c = c.cpu().numpy()[0]
+        got = {"dcdb": kb[0].cpu().numpy(), "dcdr": kr[0].cpu().numpy()}
+        if kind == 2:
+            got["dcda"] = ka[0].cpu().numpy()
+        water = m[0, 1, 0] <= 0.0
+        nchk = 0
+        for ip in range(per.size):
+            cref, uref, mm, ndiv = meta[ip]
+            if cref <= 0:
+                assert c[ip] == 0 and not got["dcdb"][ip].any()
+                continue
+            assert abs(c[ip] / cref - 1) < 2e-5, (name, w, per[ip], c[ip], cref)
+            for i, key in enumerate(("dcda", "dcdb", "dcdr")):
+                if key not in got:
+                    continue
+                ref = cport.sum_sublayers(blk[ip, i], L, int(ndiv), int(mm), water)
+                # the period's peak: the largest entry the reference itself holds, i.e. per SUBLAYER (a layer's sum may be the
+                # remainder of a cancellation between its sublayers: dc/drho of a 40 km layer, -0.111 + 0.056 + 0.038 + ... = -5e-4)
+                peak = np.abs(blk[ip, i]).max()
+                err = np.abs(got[key][ip].astype(np.float64) - ref).max() / peak
+                worst = max(worst, err)
+                assert err < 1e-4, (name, w, key, per[ip], err, small)
+                nchk += 1
+        assert nchk >= 8
+    print(f"partials vs COMMON /rar1/ {name} {w}: worst {worst:.2e} of a period's peak")
