@@ -256,6 +256,10 @@ int surfdisp_mcmc_accept_tree_device(void *stream, int C, int N, int P, int dept
  *          SURFDISP_INDEPENDENT mode: (stack, period) units) of the last solve on `workspace` took that path.
  *          Waits for `stream`. */
 int surfdisp_workspace_fallback_count(void *stream, const void *workspace, int B, int Lmax, int P, int *count);
+/*          ... and counts3[3] = {that count; brackets the root search refined with NEVILL because they may hold several roots
+ *          (vertical phase growing by more than 1 rad across the bracket); Rayleigh ellipticities evaluated again with the
+ *          reference's own arithmetic (closure cancelling, or c far below the stack's fastest S velocity)}. */
+int surfdisp_workspace_counters(void *stream, const void *workspace, int B, int Lmax, int P, int *counts3);
 
 /* ---- tuning / introspection ------------------------------------------------------------- */
 /* lanes of one wavefront that cooperate on one stack's root search (1,2,4,...,64); 0 = choose

@@ -32,7 +32,7 @@ EXPORTS = (
     "surfdisp_events_elapsed_ms", "surfdisp_stream_wait_event", "surfdisp_params_to_model_device",
     "surfdisp_params_to_model_thermal_device", "surfdisp_thermal_scratch_bytes",
     "surfdisp_mcmc_propose_device", "surfdisp_mcmc_accept_device", "surfdisp_mcmc_propose_tree_device", "surfdisp_mcmc_accept_tree_device",
-    "surfdisp_forward_kernels_device", "surfdisp_kernels_workspace_bytes", "surfdisp_workspace_fallback_count", "surfdisp_set_team", "surfdisp_get_team", "surfdisp_get_team2",
+    "surfdisp_forward_kernels_device", "surfdisp_kernels_workspace_bytes", "surfdisp_workspace_fallback_count", "surfdisp_workspace_counters", "surfdisp_set_team", "surfdisp_get_team", "surfdisp_get_team2",
     "surfdisp_device_count", "surfdisp_abi_version", "surfdisp_last_error",
     "surfdisp_kernel_name",
 )
@@ -124,6 +124,9 @@ def lib() -> ctypes.CDLL:
     L.surfdisp_thread_release.argtypes = []
     L.surfdisp_workspace_fallback_count.restype = ctypes.c_int
     L.surfdisp_workspace_fallback_count.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip]
+    if hasattr(L, "surfdisp_workspace_counters"):              # (absent from an r03 build loaded through SURFDISP_LIB_PATH for A/B runs)
+        L.surfdisp_workspace_counters.restype = ctypes.c_int
+        L.surfdisp_workspace_counters.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip]
     L.surfdisp_set_team.restype = ctypes.c_int
     L.surfdisp_set_team.argtypes = [ctypes.c_int]
     L.surfdisp_get_team.restype = ctypes.c_int

@@ -30,6 +30,7 @@ struct EnvKnobs {
                                   // evaluated again with the reference's arithmetic (0 = off)
     float ell_ambig = 3.0e-3f;    // SURFDISP_ELL_AMBIG (developer knob): ellipticity closures below this fraction of their terms' magnitude are
                                   // evaluated again with the reference's arithmetic (0 = off)
+    float ell_gmax = 25.0f;       // SURFDISP_ELL_GMAX (developer knob): ... and where 2 b^2 / c^2 of the stack's fastest layer exceeds this
     float phimulti = 1.0f;        // SURFDISP_PHIMULTI (developer knob): vertical-phase growth (rad) across a bracket beyond which NEVILL refines it
     bool fastscan = false;        // SURFDISP_FASTSCAN=1: opt every call of the process into the heuristic scan
     int device = 0;               // SURFDISP_DEVICE (fast_surf_)
@@ -58,6 +59,7 @@ struct EnvKnobs {
         if (const char *e = getenv("SURFDISP_AMBIG")) ambig = (float)atof(e);
         if (const char *e = getenv("SURFDISP_PHIMULTI")) phimulti = (float)atof(e);
         if (const char *e = getenv("SURFDISP_ELL_AMBIG")) ell_ambig = (float)atof(e);
+        if (const char *e = getenv("SURFDISP_ELL_GMAX")) ell_gmax = (float)atof(e);
         if (const char *e = getenv("SURFDISP_FASTSCAN")) fastscan = atoi(e) != 0;
         if (const char *e = getenv("SURFDISP_DEVICE")) device = atoi(e);
         if (const char *e = getenv("SURFDISP_BALANCE")) balance = atoi(e);
@@ -281,6 +283,19 @@ int surfdisp_workspace_fallback_count(void *stream, const void *workspace, int B
     return SURFDISP_SUCCESS;
 }
 
+// introspection: {stacks handed to the exact fallback kernel, brackets sent to NEVILL because the vertical phase grows by more
+// than SURFDISP_PHIMULTI across them (-DSD_AMBIG builds: + scan trials evaluated again), ellipticities evaluated again with the
+// reference's arithmetic} of the last solve on `workspace`.  Waits for `stream`.
+int surfdisp_workspace_counters(void *stream, const void *workspace, int B, int Lmax, int P, int *counts3)
+{
+    if (!workspace || !counts3 || B < 1 || Lmax < 2 || P < 1) { set_err("bad argument"); return SURFDISP_ERR_INVALID; }
+    const Carve w = carve(const_cast<void *>(workspace), B, Lmax, P);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SD_HIP(hipMemcpyAsync(counts3, w.fb_count, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SD_HIP(hipStreamSynchronize(s));
+    return SURFDISP_SUCCESS;
+}
+
 static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
                                const float *model, int P, const float *per, int kind,
                                float *c, float *u, int *status,
@@ -349,10 +364,10 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     else          { ph.msrc = w.mdl;  ph.ms_b = 1;         ph.ms_f = (long)Lmax * B; ph.ms_i = B; }
     // (two-lane teams compute their ellipticities themselves but record the history too: the pairs whose closure cancels
     // are redone by the ellipticity kernel)
-    const bool ell_fix = ell_in && !strict && kn.ell_kernel != 0 && kn.ell_ambig > 0.0f;
+    const bool ell_fix = ell_in && !strict && kn.ell_kernel != 0 && kn.ell_ambig != 0.0f;
     ph.hist = (ell_k || ell_fix) ? w.hist : nullptr;
     ph.lockstep = kn.lockstep >= 0 ? kn.lockstep : 1;
-    ph.ambig = kn.ambig; ph.phimulti = kn.phimulti; ph.amb_count = w.amb_count; ph.ell_ambig = ell_fix ? kn.ell_ambig : 0.0f;
+    ph.ambig = kn.ambig; ph.phimulti = kn.phimulti; ph.amb_count = w.amb_count; ph.ell_ambig = ell_fix ? kn.ell_ambig : 0.0f; ph.ell_gmax = kn.ell_gmax;
     SD_HIP(sd::launch_phase(s, kind, G, indep, ph));
     // the exact fallback re-solves what the production kernel listed (normally nothing: idle blocks exit at once)
     ph.overlap = 0; ph.fast = 0;
@@ -360,7 +375,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     SD_HIP(sd::launch_phase_exact(s, kind, indep, ph));
     if (ev) SD_HIP(hipEventRecord(ev[2], s));              // [ev1, ev2] = the root search (+ its idle fallback launch)
     if (ell_k || ell_fix) {
-        sd::EllipArgs ea{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.hist, w.nsolved, w.ratio, kn.ell_ambig, ell_k ? 0 : 1, w.amb_count};
+        sd::EllipArgs ea{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.hist, w.nsolved, w.ratio, kn.ell_ambig, ell_k ? 0 : 1, w.amb_count, kn.ell_gmax, w.ovf};
         SD_HIP(sd::launch_ellip(s, ea));
     }
 #ifdef SD_WAVECLOCK

@@ -59,6 +59,7 @@ struct PhaseArgs {
     float phimulti;       // a bracket across which the vertical phase grows by more than this (rad) goes to NEVILL
     int *amb_count;       // nullptr, or [2]: number of scan trials / of ellipticities evaluated again (statistics)
     float ell_ambig;      // in-kernel ellipticity passes: a closure below this fraction of its terms marks the pair for the ellipticity kernel
+    float ell_gmax;       // ... and so does g = 2 b^2 / c^2 of the stack's fastest layer beyond this
 #ifdef SD_WAVECLOCK
     unsigned long long *wclk;   // developer build: [waves][2] s_memrealtime at wavefront start / end
 #endif
@@ -97,9 +98,11 @@ struct EllipArgs {
     const int *hist;      // [P][B], see PhaseArgs
     const int *nsolved;   // [B]
     float *ratio;         // [P][B]
-    float ell_ambig;      // a closure below this fraction of its terms: both passes again with the reference's arithmetic (0: never)
+    float ell_ambig;      // a closure below this fraction of its terms: both passes again with the reference's arithmetic (0: never; < 0: always)
     int only_flagged;     // 1: the root search wrote the ellipticities itself; redo only the pairs it marked (bit 30 of hist)
     int *amb_count;       // nullptr, or [2] statistics, see PhaseArgs
+    float ell_gmax;       // ... and where g = 2 b^2 / c^2 of the stack's fastest layer exceeds this
+    const float *ovf;     // [3][B] prep statistics (entry 2: 4 ln(2 bmax^2))
 };
 hipError_t launch_ellip(hipStream_t s, const EllipArgs &a);
 

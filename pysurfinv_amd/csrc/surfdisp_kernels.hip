@@ -947,6 +947,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     int nv_nev = 1, nv_m = 1, nv_ic = 0;
     bool defer = false;                // !EXACT: this stack goes to the exact fallback kernel
     bool ell_flag = false;             // in-kernel ellipticity of the period at hand: to be redone by the ellipticity kernel
+    // ... whenever c^2 is below this: 2 b^2 / c^2 of the stack's fastest layer beyond A.ell_gmax (read once: the prep kernel's statistic)
+    const float ell_c2min = (want_ratio && !EXACT && team_valid && A.ovf != nullptr && A.ell_ambig != 0.0f)
+                                ? __expf(0.25f * A.ovf[2 * (size_t)B + b]) / A.ell_gmax : 0.0f;
 
     // (re)build the working stack for period k over the first nflat layers only -- the reference
     // refreshes just the layers inside the previous period's effective half space and leaves the
@@ -990,20 +993,44 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     };
 
     // growth of the vertical phase between two trial velocities over the first mm - 1 layers of the working stack (see the
-    // bracket branch of the scan); every lane of the team calls it
+    // bracket branch of the scan); every lane of the team calls it.  The same walk notes which P and S velocities of the first
+    // mm layers lie INSIDE the bracket (kink_possible) - see REFINE's acceptance test.
+    bool kink_possible = false;
     auto bracket_phase = [&](float c1, float c2, int mm) -> float {
         const float om = 6.2831853f * __builtin_amdgcn_rcpf(T);
         const float i1 = __builtin_amdgcn_rcpf(c1 * c1), i2 = __builtin_amdgcn_rcpf(c2 * c2);
+        const float klo = i2 * 0.999998f, khi = i1 * 1.000002f;
         float sum = 0.0f;
-        for (int i = j; i < mm - 1; i += G) {
-            const float od = om * W_D(i);
+        bool hit = false;
+        for (int i = j; i < mm; i += G) {
+            const float od = (i < mm - 1) ? om * W_D(i) : 0.0f;                  // (the half space: no thickness, but a velocity)
             const float ib2 = (KIND == 2) ? W_IB2(i) : W_IR(i) * W_R(i);       // 1/b^2 (0: liquid)
             sum += od * (sqrt_hw(fmaxf(ib2 - i2, 0.0f)) - sqrt_hw(fmaxf(ib2 - i1, 0.0f)));
-            if (KIND == 2) { const float ia2 = W_IA2(i); sum += od * (sqrt_hw(fmaxf(ia2 - i2, 0.0f)) - sqrt_hw(fmaxf(ia2 - i1, 0.0f))); }
+            hit = hit || (ib2 >= klo && ib2 <= khi);
+            if (KIND == 2) {
+                const float ia2 = W_IA2(i);
+                sum += od * (sqrt_hw(fmaxf(ia2 - i2, 0.0f)) - sqrt_hw(fmaxf(ia2 - i1, 0.0f)));
+                hit = hit || (ia2 >= klo && ia2 <= khi);
+            }
         }
 #pragma unroll
         for (int d = G >> 1; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+        kink_possible = (__ballot(hit) & tmask) != 0ull;
         return fabsf(sum);
+    };
+
+    // is 1/v^2 of a P or S velocity of the first mm layers of the working stack within [ilo, ihi]?  (every lane of the team)
+    auto kink_inside = [&](float ilo, float ihi, int mm) -> bool {
+        int hit = 0;
+#pragma unroll 1
+        for (int i = j; i < mm; i += G) {
+            const float ib2 = (KIND == 2) ? W_IB2(i) : W_IR(i) * W_R(i);
+            hit |= (ib2 >= ilo && ib2 <= ihi) ? 1 : 0;
+            if (KIND == 2) { const float ia2 = W_IA2(i); hit |= (ia2 >= ilo && ia2 <= ihi) ? 1 : 0; }
+        }
+#pragma unroll
+        for (int d = G >> 1; d > 0; d >>= 1) hit |= __shfl_xor(hit, d);
+        return hit != 0;
     };
 
     // Rayleigh, production kernel: can a matrix ENTRY of the reference overflow fp32 in this period although the
@@ -1152,7 +1179,13 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
 #endif
             if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, LS, S, mmj, cj, Tl, start)
                                        : delta_rayleigh<(G != 2) && !FAST>(wl, LS, S, mmj, cj, Tl, start, phj, &vmag, want_mag);
-            else           val = EXACT ? delta_love_ref(wl, LS, S, mmj, cj, Tl) : delta_love<CERT>(wl, LS, S, mmj, cj, Tl, phj, kcj, kuncj, coarse, &vmag);   // counts only where they are compared: coarse passes
+            else           val = EXACT ? delta_love_ref(wl, LS, S, mmj, cj, Tl) : delta_love<CERT>(wl, LS, S, mmj, cj, Tl, phj, kcj, kuncj, coarse,
+#ifdef SD_AMBIG
+                                                                                                      &vmag
+#else
+                                                                                                      nullptr
+#endif
+                                                                                                      );   // counts only where they are compared: coarse passes
         }
         // (-DSD_AMBIG builds only, see DESIGN.md.)  A scan trial whose value is the remainder of a cancellation - |value| below A.ambig of the terms it is the sum of -
         // has a SIGN within the rounding of the production recursion, and the scan decides on signs (calcul.f:157-167): a
@@ -1169,7 +1202,13 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         // ... and the in-kernel ellipticity passes (two-lane teams) likewise: a closure that is the remainder of a cancellation
         // marks the (stack, period) for the ellipticity kernel, which evaluates both passes with the reference's arithmetic
         // on the replayed working stack (see there)
-        const bool ell_amb = !EXACT && want_ratio && eval && st == ST_ELLIP && A.ell_ambig > 0.0f && fabsf(val) < A.ell_ambig * vmag;
+#ifdef SD_NO_ELLG
+        const bool ell_amb = false;
+#else
+        const bool ell_amb = !EXACT && want_ratio && eval && st == ST_ELLIP && A.ell_ambig != 0.0f &&
+                             (A.ell_ambig < 0.0f || fabsf(val) < A.ell_ambig * vmag ||
+                              cj * cj < ell_c2min);                                       // see surfdisp_ellip_kernel
+#endif
 #ifdef SD_WAVECLOCK
         wcyc_eval += __builtin_readcyclecounter() - we0;
 #endif
@@ -1361,10 +1400,15 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 // the G points of the first refine pass) only sees roots further apart than its points.  r04 soak: 4e-3 of
                 // the soft-sediment family's Love stacks came back on another overtone (1 .. 15 % off) from teams of <= 8
                 // lanes.  The phase is summed by the team, once per bracket (a layer per lane and turn).
-                if (EXACT || bracket_phase(p0c, cb, mm_frozen) > A.phimulti) {   // NEVILL's prologue, surfa.f:12-16 (del1 is the scan's value, whatever layer dropping it was computed with - as in the reference)
+                #ifdef SD_NO_PHASEMULTI
+                if (EXACT) {
+#else
+                if (EXACT || bracket_phase(p0c, cb, mm_frozen) > A.phimulti) {
+#endif   // NEVILL's prologue, surfa.f:12-16 (del1 is the scan's value, whatever layer dropping it was computed with - as in the reference)
                     nv_ic = 0; nv_nev = 1; nv_m = 1;
                     croot = (p0c + cb) / 2.0f;                 // c3, evaluated by the next pass
                     st = ST_NEVILL;
+                    if (!EXACT && j == 0 && A.amb_count) atomicAdd(A.amb_count, 1);     // (statistics)
                 }
             } else if (fl >= 0) {
                 failed = true;                                 // label 250
@@ -1512,7 +1556,27 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                     agree = (t2 >= 0.0f) && (t2 <= w) && (fabsf(t - t2) <= A.atol);
                 }
                 ++passes;                                          // hard bound: fp32 cannot resolve <1 ulp
-                if (!(w > 1.0e-6f) || (!(w > A.wtol) && agree) || passes > 64) {
+                // ... and never across a KINK: where c passes a layer's P or S velocity the layer turns from evanescent to
+                // oscillatory and the secular function behaves like sign(x) sqrt|x| there (the half-space closure is linear in
+                // sqrt|c^2/b^2 - 1|).  With such a velocity among the points an estimate is built from, all three-point
+                // estimates miss alike and still agree (ragged fixture, 60 s: root 5e-6 km/s below a layer's S velocity; teams
+                // of 16 lanes accepted a 3.5e-5 bracket and came out 8e-6 off, 1e-3 of U; NEVILL - and teams of any other size -
+                // within 6e-7).
+                bool accept = !(w > 1.0e-6f) || passes > 64;
+                if (!accept && !(w > A.wtol) && agree) {
+#ifndef SD_NO_KINK
+                    // (the bracket itself: with the kink between the bracket and ONE of the outer points the two estimates - one
+                    // built across it, one not - disagree by themselves.  Whether ANY velocity lies inside the SCAN's bracket was
+                    // noted when it was found (bracket_phase; usually none); only then the working stack is walked again.)
+                    if (kink_possible) {
+                        const float jlo = __builtin_amdgcn_rcpf(p0c * p0c) * 1.000002f, jhi = __builtin_amdgcn_rcpf(cb * cb) * 0.999998f;
+                        accept = !kink_inside(jhi, jlo, mm_frozen);
+                    } else accept = true;
+#else
+                    accept = true;
+#endif
+                }
+                if (accept) {
                     croot = p0c + (inside ? t : ts);
                     if (p0c >= 16.0f) fatal = true;                // NEVILL's 50 cycles, see above
                     else if (croot <= W_B(mm_frozen - 1)) {        // calcul.f:191
@@ -1683,13 +1747,21 @@ __global__ __launch_bounds__(256) void surfdisp_ellip_kernel(EllipArgs A)
     bool exact = A.only_flagged != 0;
     if (!exact) {
         const RTrial t = ray_trial(c, T);
-        Replay r = r0;
+        int kk = k;                                          // period whose rebuild last refreshed the layer at hand
+        int nflat = hk & 0xffff;
+        float lnT = r0.lnT;
         RState s2{}, s3{};
         float phi = 0.0f, rho_prev = 0.0f;
         RLyr y{};
         float rho_i = 0.0f;
         for (int i = 0; i <= last; ++i) {
-            const LayerV v = layer(i, r);
+            while (nflat <= i && kk > 0) {                   // an earlier rebuild: period 0 refreshed all n layers
+                --kk;
+                const int h = A.hist[(size_t)kk * B + b];
+                nflat = (h < 0) ? n : (h & 0xffff);
+                lnT = logf(1.0f / A.per[kk]);
+            }
+            const LayerV v = layer_derive(layer_load(A.mdl, fs, (size_t)i * B + b), lnT, i == nflat - 1);
             rho_prev = rho_i;
             rho_i = v.rho;
             y.sv = v.b; y.d = v.d;
@@ -1709,7 +1781,13 @@ __global__ __launch_bounds__(256) void surfdisp_ellip_kernel(EllipArgs A)
         const float rp = (last >= 1) ? rho_prev : 0.0f;
         float m2 = 0.0f, m3 = 0.0f;
         v2 = ray_close(s2, t, y, rho_i, rp, 2, &m2); v3 = ray_close(s3, t, y, rho_i, rp, 3, &m3);
-        exact = (A.ell_ambig > 0.0f) && (fabsf(v2) < A.ell_ambig * m2 || fabsf(v3) < A.ell_ambig * m3);
+        // ... or where c is far below a layer's S velocity: g = 2 b^2 / c^2 of that layer is in the hundreds and the recursion's
+        // u1 = g^2 b1 + 2 g h3 - h5 (as the reference's a11 .. a51, differently arranged) cancels inside the LAYER steps - soft
+        // sediments over rock, c = 0.2 .. 0.4 km/s: the production ellipticity came out 3e-4 .. 4e-3 off the reference's (1e-4
+        // .. 4e-4 of U) with an unremarkable closure.  The stack's largest flattened S velocity is the prep kernel's statistic.
+        const float b2max = A.ovf ? 0.5f * __expf(0.25f * A.ovf[2 * (size_t)B + b]) : 0.0f;
+        exact = (A.ell_ambig < 0.0f) ||
+                ((A.ell_ambig > 0.0f) && (fabsf(v2) < A.ell_ambig * m2 || fabsf(v3) < A.ell_ambig * m3 || 2.0f * b2max > A.ell_gmax * c * c));
     }
     if (exact) {
         Replay r = r0;

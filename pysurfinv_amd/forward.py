@@ -165,6 +165,16 @@ class BatchPlan:
                                                                     self.B, self.L, self.P, ctypes.byref(n)))
         return int(n.value)
 
+    def counters(self):
+        """(stacks through the exact fallback kernel, brackets refined with NEVILL by the phase test, ellipticities evaluated
+        again with the reference's arithmetic) of the last solve (``surfdisp_workspace_counters``; synchronises the stream)."""
+        n = (ctypes.c_int * 3)()
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        with self.torch.cuda.device(self.device):
+            _lib.check(_lib.lib().surfdisp_workspace_counters(ctypes.c_void_p(stream), ctypes.c_void_p(getattr(self, '_last_ws', self.workspace).data_ptr()),
+                                                              self.B, self.L, self.P, n))
+        return tuple(int(x) for x in n)
+
     def run_kernels(self, model, periods, kind=2, nlay=None, want_vp=True, want_rho=True, small_workspace=False):
         """Forward solve + analytic partial derivatives of the phase velocity
         (``surfdisp_forward_kernels_device``): returns (c, u, status, dcdb, dcda, dcdr) with the

@@ -532,17 +532,20 @@ def test_soak_family_fixtures(hip, ref_families, family):
     regime).  Zero patterns and root choice as the reference's, c within tolerance, and the group velocity within 1e-4
     of the reference's own at EVERY entry (no quantiles) - except the entries of tests/golden/u_exceptions_families.json
     (tests/golden/make_golden_spread_families.py records for each: the reference's own FMA / non-FMA spread, |dlnU/dlnc|,
-    the HIP path's error in default and SURFDISP_STRICT mode): six at which the reference's two builds disagree with
-    each other by 4e-5..2.8e-3 and / or |dlnU/dlnc| is 160..1100 (held to 5e-3), and three soft-sediment guided-wave
-    entries (c ~ 0.25 km/s) at which the production ellipticity costs 1.0..1.5e-4 of U (held to 2e-4; SURFDISP_STRICT
-    is inside the bar there)."""
+    the HIP path's error in default and SURFDISP_STRICT mode).  Since r04 the list holds FIVE entries, every one of them a
+    (stack, period) at which the reference's own two builds disagree with each other by 4e-5 .. 2.8e-3 (|dlnU/dlnc| 160 ..
+    1100; SURFDISP_STRICT misses there as the default does); they are held to 5e-3.  The r03 list's other four entries are
+    inside the 1e-4 bar now: three soft-sediment guided-wave entries (c ~ 0.25 km/s) whose ellipticity is evaluated with the
+    reference's own arithmetic (surfdisp_ellip_kernel: c far below the stack's fastest S velocity), and one entry whose root
+    lies 5e-6 km/s from a layer's S velocity (the refinement no longer interpolates across such a kink)."""
     from pysurfinv_amd import _lib
     d = ref_families[family]
     nbad_max, tol_c = FAMILY_BARS[family]
     B, P = d["c"].shape
     listed = np.zeros((B, P)); own = np.zeros((B, P), bool)
     for b, k, why in FAMILY_EXCEPTIONS.get(family, ()):
-        listed[b, k] = 2e-4 if why.startswith("production ellipticity") else 5e-3
+        assert why.startswith("reference builds disagree"), why     # (the only kind of exception left)
+        listed[b, k] = 5e-3
     for team in (0, 1, 4, 16):
         _lib.lib().surfdisp_set_team(team)
         try:
@@ -762,7 +765,9 @@ def test_default_mode_agrees_with_strict_mode_at_full_size(hip, kind, B, L):
     assert plan.fallback_count() == 0
     cd, ud = plan.c.cpu().numpy(), plan.u.cpu().numpy()
     assert (cs > 0).all() and np.array_equal(cd > 0, cs > 0)
-    assert np.abs(cd.astype(np.float64) / cs - 1.0).max() < 1e-5
+    # (L64: 9.3e-6 - brackets that hold a layer's S velocity are refined on signs down to the rounding of a 64-layer
+    # recursion, where the two arithmetics' sign changes sit up to 1e-5 apart; r03, which interpolated across the kink: 5.4e-6)
+    assert np.abs(cd.astype(np.float64) / cs - 1.0).max() < 1.3e-5
     eu = np.abs(ud.astype(np.float64) / us - 1.0)
     assert eu.max() < 1e-4 and np.quantile(eu, 0.999) < 5e-6
 
@@ -892,3 +897,37 @@ def test_ellipticity_output_abi3(hip, ref_cases, case):
     c, u, st, r = plan.run(dm, dp, kind=1, want_ratio=True)
     torch.cuda.synchronize()
     assert float(r.abs().max()) == 0.0
+
+
+def test_soak_offender_fixture_every_team_size(hip):
+    """The stacks on which the r03 library returned ANOTHER ROOT than the reference (tests/golden/ref_offenders.npz, from
+    the r04 differential soak; reference outputs by make_golden_offenders.py): water layer over soft sediments with
+    |Delta| ~ 1e20 (the refinement's reciprocals flushed to zero and the bracket's low end came back), and Love overtones
+    1e-3 km/s apart (several roots per bracket, invisible to a small team's subdivision).  Every stack whose roots are
+    DEFINED by the reference's formulas (its FMA build and two other roundings of exp / flattening agree to 2e-5) must come
+    back on the reference's roots - zero pattern equal, c within 1e-4 - for every team size, and at most one of them may
+    miss for any team size (the soak's residual rate on such stacks is 1e-6)."""
+    from pysurfinv_amd import _lib
+    f = np.load(os.path.join(GOLDEN, "ref_offenders.npz"))
+    nst = len(f["nlay"])
+    r03_bad = 0
+    bad = {}
+    for q in range(nst):
+        n, P, kind = int(f["nlay"][q]), int(f["P"][q]), int(f["kind"][q])
+        m = np.ascontiguousarray(f["model"][q][None, :, :n]); per = f["per"][q][:P]; cr = f["c"][q][:P]
+        with np.errstate(all="ignore"):
+            r03_bad += int((np.abs(f["c_r03"][q][:P] / cr - 1)[cr > 0] > 1e-4).any())
+        if not f["defined"][q]:
+            continue
+        for team in (0, 1, 2, 4, 8, 16, 64):
+            _lib.lib().surfdisp_set_team(team)
+            try:
+                c, u, st = hip.forward_batch(m, per, kind)
+            finally:
+                _lib.lib().surfdisp_set_team(0)
+            with np.errstate(all="ignore"):
+                ok = np.array_equal(c[0] > 0, cr > 0) and (np.abs(c[0][cr > 0] / cr[cr > 0] - 1) < 1e-4).all()
+            if not ok:
+                bad.setdefault(q, []).append(team)
+    assert r03_bad == nst                                      # (the fixture is what it says: every stack was off in r03)
+    assert len(bad) <= 1, bad

@@ -189,3 +189,14 @@ def test_oracle_partials_bit_exact_vs_reference_common_block(name, wave):
                 assert np.array_equal(o[k][:int(mm)], ref), (name, wave, T, k)
             nz += int(np.count_nonzero(ref))
     assert nz > 50
+
+
+def test_oracle_bit_exact_on_the_soak_offender_fixture():
+    """tests/golden/ref_offenders.npz (stacks on which the r03 library returned another root than the reference;
+    make_golden_offenders.py): the restatement returns the reference's phase velocities bit for bit."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_offenders.npz"))
+    for q in range(len(f["nlay"])):
+        n, P = int(f["nlay"][q]), int(f["P"][q])
+        c, u, st = cport.forward_batch(np.ascontiguousarray(f["model"][q][None, :, :n]), f["per"][q][:P], int(f["kind"][q]))
+        assert np.array_equal(c[0], f["c"][q][:P]), q
