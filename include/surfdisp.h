@@ -232,6 +232,23 @@ int surfdisp_mcmc_accept_device(void *stream, int C, int N, int P, const float *
                                 const double *c_obs, const double *uncer, const unsigned char *mask, int obs_per_chain,
                                 const double *p1, double *p0, double *chi0, double *row, long row_stride,
                                 unsigned long long seed, unsigned long long counter, int first, long chain0);
+/* ---- (6c) prior predicates on the device, so that a sampler with a prior keeps its lock step there.  The reference redraws a
+ *   proposal until `isgood(model)` holds (MCinv.perturb / reset, models.py:192-219: up to 1000 Gaussian tries, then uniform
+ *   draws); its model classes build `isgood` from a few GENERIC tests on the grid points of seisPropGrids (models.py:294-320):
+ *   Vs increasing inside a layer group (monoIncrease), no drop of Vs across a group boundary, Vs below a cap.
+ *   surfdisp_prior_device evaluates those for every chain: flags [L] per OUTPUT layer of the params->stack descriptor (bit 0: Vs
+ *   must increase across the layer; bit 1: ... and on to the top of the next layer; bit 2: must not drop to the top of the next
+ *   layer; bit 3: both its points at most vs_max).  tags [C] (unsigned char): a chain that breaks a rule gets tags[c] = mark_tag (1..255); with
+ *   only_tag >= 0 only the chains with tags[c] >= only_tag are looked at - the rounds of one step use rising tags (the caller
+ *   clears tags once per step), so nothing needs clearing between rounds.  Models with a static layer structure, no thermal layer.
+ *   surfdisp_mcmc_propose_masked_device redraws the chains with tags[c] == tag only (try number `attempt` of this step: its own
+ *   random numbers; mode 0 bounded Gaussian step, 1 uniform prior draw, 2 the chain's state itself), leaving the other rows of
+ *   `out` as they are.  pysurfinv_amd.mcmc.MetropolisBatch(isgood=PriorRules(...)) strings them into masked redraw rounds. */
+int surfdisp_prior_device(void *stream, int C, int N, int L, const double *params, const int *idesc, const double *fdesc,
+                          const int *flags, double vs_max, int only_tag, int mark_tag, unsigned char *tags);
+int surfdisp_mcmc_propose_masked_device(void *stream, int C, int N, const double *p, const double *vmin, const double *vmax,
+                                        const double *step, unsigned long long seed, unsigned long long counter, int attempt, int mode,
+                                        const unsigned char *tags, int tag, double *out, long chain0);
 /* The SPECULATIVE lock step for few chains (a lock step of 100 chains leaves the chip idle, so it costs no more to solve
  * several proposals per chain): propose_tree draws the binary tree of the next `depth` (1..4) accept / reject outcomes -
  * node k's proposal from the state its branch would be in (node 0: the chain's state; child 2k+1 "accepted": proposal k;

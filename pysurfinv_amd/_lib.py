@@ -31,7 +31,7 @@ EXPORTS = (
     "surfdisp_forward_batch_device_events", "surfdisp_events_create", "surfdisp_events_destroy",
     "surfdisp_events_elapsed_ms", "surfdisp_stream_wait_event", "surfdisp_params_to_model_device",
     "surfdisp_params_to_model_thermal_device", "surfdisp_thermal_scratch_bytes",
-    "surfdisp_mcmc_propose_device", "surfdisp_mcmc_accept_device", "surfdisp_mcmc_propose_tree_device", "surfdisp_mcmc_accept_tree_device",
+    "surfdisp_mcmc_propose_device", "surfdisp_mcmc_accept_device", "surfdisp_prior_device", "surfdisp_mcmc_propose_masked_device", "surfdisp_mcmc_propose_tree_device", "surfdisp_mcmc_accept_tree_device",
     "surfdisp_forward_kernels_device", "surfdisp_kernels_workspace_bytes", "surfdisp_workspace_fallback_count", "surfdisp_workspace_counters", "surfdisp_set_team", "surfdisp_get_team", "surfdisp_get_team2",
     "surfdisp_device_count", "surfdisp_abi_version", "surfdisp_last_error",
     "surfdisp_kernel_name",
@@ -112,6 +112,13 @@ def lib() -> ctypes.CDLL:
     u64 = ctypes.c_ulonglong
     L.surfdisp_mcmc_propose_device.restype = ctypes.c_int
     L.surfdisp_mcmc_propose_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, u64, u64, ctypes.c_int, vp, ctypes.c_long]
+    if hasattr(L, "surfdisp_prior_device"):                    # (absent from an r03 build loaded through SURFDISP_LIB_PATH for A/B runs)
+        L.surfdisp_mcmc_propose_masked_device.restype = ctypes.c_int
+        L.surfdisp_mcmc_propose_masked_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, u64, u64, ctypes.c_int, ctypes.c_int,
+                                                          vp, ctypes.c_int, vp, ctypes.c_long]
+        L.surfdisp_prior_device.restype = ctypes.c_int
+        L.surfdisp_prior_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_double, ctypes.c_int,
+                                            ctypes.c_int, vp]
     L.surfdisp_mcmc_accept_device.restype = ctypes.c_int
     L.surfdisp_mcmc_accept_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int,
                                               vp, vp, vp, vp, ctypes.c_long, u64, u64, ctypes.c_int, ctypes.c_long]

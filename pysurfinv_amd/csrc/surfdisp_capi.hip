@@ -491,8 +491,37 @@ int surfdisp_mcmc_propose_device(void *stream, int C, int N, const double *p, co
                                  const double *step, unsigned long long seed, unsigned long long counter, int reset, double *out, long chain0)
 {
     if (C < 1 || N < 1 || !p || !vmin || !vmax || !step || !out || chain0 < 0) { set_err("surfdisp_mcmc_propose_device: bad argument"); return SURFDISP_ERR_INVALID; }
-    sd::McmcProposeArgs a{C, N, p, vmin, vmax, step, seed, counter, reset ? 1 : 0, out, chain0, 1};
+    sd::McmcProposeArgs a{C, N, p, vmin, vmax, step, seed, counter, reset ? 1 : 0, out, chain0, 1, nullptr, 0, 0};
     SD_HIP(sd::launch_mcmc_propose(static_cast<hipStream_t>(stream), a));
+    return SURFDISP_SUCCESS;
+}
+
+// masked redraw of the chains the prior kernel tagged (tags[c] == tag; see surfdisp_prior_device); mode 0: bounded Gaussian step,
+// 1: uniform prior draw, 2: the chain's state itself
+int surfdisp_mcmc_propose_masked_device(void *stream, int C, int N, const double *p, const double *vmin, const double *vmax,
+                                        const double *step, unsigned long long seed, unsigned long long counter, int attempt, int mode,
+                                        const unsigned char *tags, int tag, double *out, long chain0)
+{
+    if (C < 1 || N < 1 || !p || !vmin || !vmax || !step || !out || !tags || chain0 < 0 || attempt < 0 || attempt > 1023 || mode < 0 || mode > 2 ||
+        tag < 1 || tag > 255) {
+        set_err("surfdisp_mcmc_propose_masked_device: bad argument"); return SURFDISP_ERR_INVALID;
+    }
+    sd::McmcProposeArgs a{C, N, p, vmin, vmax, step, seed, counter, mode, out, chain0, 1, tags, attempt, tag};
+    SD_HIP(sd::launch_mcmc_propose(static_cast<hipStream_t>(stream), a));
+    return SURFDISP_SUCCESS;
+}
+
+// The generic prior predicates on the device (csrc/surfdisp_layers.hip, surfdisp_prior_kernel): tags[c] = mark_tag where chain c's
+// model breaks a rule; only_tag >= 0: only chains with tags[c] >= only_tag are looked at.  Static-structure models, no thermal layer.
+int surfdisp_prior_device(void *stream, int C, int N, int L, const double *params, const int *idesc, const double *fdesc,
+                          const int *flags, double vs_max, int only_tag, int mark_tag, unsigned char *tags)
+{
+    if (C < 1 || N < 0 || L < 1 || L > SURFDISP_NLAY_MAX || !params || !idesc || !fdesc || !flags || !tags || mark_tag < 1 || mark_tag > 255 ||
+        only_tag >= mark_tag) {
+        set_err("surfdisp_prior_device: bad argument"); return SURFDISP_ERR_INVALID;
+    }
+    sd::LayersArgs a{C, N, params, idesc, fdesc, nullptr, nullptr};
+    SD_HIP(sd::launch_prior(static_cast<hipStream_t>(stream), a, L, flags, vs_max, only_tag, mark_tag, tags));
     return SURFDISP_SUCCESS;
 }
 
@@ -502,7 +531,7 @@ int surfdisp_mcmc_propose_tree_device(void *stream, int C, int N, int depth, con
     if (C < 1 || N < 1 || depth < 1 || depth > sd::SD_MCMC_MAX_DEPTH || !p || !vmin || !vmax || !step || !out || chain0 < 0) {
         set_err("surfdisp_mcmc_propose_tree_device: bad argument (1 <= depth <= 4)"); return SURFDISP_ERR_INVALID;
     }
-    sd::McmcProposeArgs a{C, N, p, vmin, vmax, step, seed, counter, 0, out, chain0, depth};
+    sd::McmcProposeArgs a{C, N, p, vmin, vmax, step, seed, counter, 0, out, chain0, depth, nullptr, 0, 0};
     SD_HIP(sd::launch_mcmc_propose(static_cast<hipStream_t>(stream), a));
     return SURFDISP_SUCCESS;
 }
@@ -831,6 +860,9 @@ int surfdisp_forward_batch(int device, int B, int Lmax, const int *nlay, const f
             if (status) memcpy(status, h + o_st, ni);
         }
     } while (0);
+    // an error exit may leave copies / kernels queued on the thread's cached stream that still write into the caller's pageable
+    // arrays or into the buffer the next call reuses: drain it before returning (the result is the error already recorded)
+    if (ret != SURFDISP_SUCCESS) (void)hipStreamSynchronize(s);
     if (!small && g_pipe.cap > PIPE_KEEP_MAX) g_pipe.release();
     return ret;
 }

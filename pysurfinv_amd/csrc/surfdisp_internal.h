@@ -136,6 +136,9 @@ struct McmcProposeArgs {
     double *out;            // [C][N]
     long chain0;            // global index of chain 0 of this launch (keys the random streams: a sampler split into chain groups draws what the unsplit one draws)
     int depth;              // <= 1: one proposal per chain; d > 1: the speculative tree of 2^d - 1 proposals (out [C][2^d-1][N])
+    const unsigned char *redo;   // nullptr, or [C]: only chains with redo[c] == redo_tag draw (masked redraw, depth 1)
+    int attempt;            // ... try number of this step: its own random numbers
+    int redo_tag;
 };
 struct McmcAcceptArgs {
     int C, N, P;
@@ -158,6 +161,7 @@ struct McmcAcceptArgs {
 hipError_t launch_mcmc_propose(hipStream_t s, const McmcProposeArgs &a);
 hipError_t launch_mcmc_accept(hipStream_t s, const McmcAcceptArgs &a);
 hipError_t launch_layers(hipStream_t s, const LayersArgs &a, int L);
+hipError_t launch_prior(hipStream_t s, const LayersArgs &a, int L, const int *flags, double vs_max, int only_tag, int mark_tag, unsigned char *tags);
 hipError_t launch_thermal(hipStream_t s, const LayersArgs &a);
 
 // lanes per workgroup of the root search.  Nothing in it synchronises across wavefronts, so any multiple of 64

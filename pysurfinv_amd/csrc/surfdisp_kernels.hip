@@ -817,7 +817,9 @@ __device__ __forceinline__ int drop_layers(const float *wq, const int LS, const 
 // ================================================================================== K1: phase
 // ST_WREF / ST_WEND (lock step, see PhaseArgs::lockstep): a team that has its bracket / its root waits for the other teams
 // of its wavefront, so that the refine pass and the end-of-period block run ONCE per period for all of them
-enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3, ST_NEVILL = 4, ST_WREF = 5, ST_WEND = 6 };
+// ST_NEVILL0 (Love, production kernel): the pass before NEVILL's first in which the bracket's two end values are evaluated again with
+// the reference's arithmetic (see the evaluation block)
+enum { ST_SCAN = 0, ST_REFINE = 1, ST_ELLIP = 2, ST_DONE = 3, ST_NEVILL = 4, ST_WREF = 5, ST_WEND = 6, ST_NEVILL0 = 7 };
 
 
 // INDEP = false: "faithful" - a team owns a stack and walks its periods in order (reference
@@ -1126,6 +1128,10 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 for (int i = 0; i < G; ++i) if (i < nadd) cj = cj + DC;
             }
             mmj = nodrop ? (n < 2 ? 2 : n) : drop_layers(wq, LS, S, n, cj, T);   // idrop=0 before every scan trial
+        } else if (st == ST_NEVILL0) {
+            // the scan's two end values again (del1 with the layer dropping of ITS trial, del2's is the frozen one)
+            const bool hi = (G == 1) ? (sub != 0) : ((j & 1) != 0);
+            cj = hi ? cb : p0c; mmj = hi ? mm_frozen : p0mm;
         } else if (st == ST_NEVILL) {
             cj = croot; mmj = mm_frozen;                       // NEVILL's c3, idrop = 1
         } else if (st == ST_REFINE) {
@@ -1179,6 +1185,13 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
 #endif
             if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, LS, S, mmj, cj, Tl, start)
                                        : delta_rayleigh<(G != 2) && !FAST>(wl, LS, S, mmj, cj, Tl, start, phj, &vmag, want_mag);
+            // Love, NEVILL passes of the production kernel: DLTAR1 statement by statement on the production working stack (it holds
+            // b, rho, d as the exact kernel's does).  A bracket goes to NEVILL because it may hold several roots, and which of them
+            // NEVILL lands on depends on the VALUES it sees (its 10 x rule, its interpolation) - with e^{kd} of hundreds of km of
+            // layer the production recursion's values differ from the reference's by whole orders of magnitude, or are inf where
+            // those are finite (r04 soak, thick-layer family, Love: 2e-4 of the stacks on another overtone with the production
+            // values, 1.4e-2 before there was a NEVILL for such brackets at all).
+            else if (!EXACT && (st == ST_NEVILL || st == ST_NEVILL0)) val = delta_love_ref_body(wl, LS, S, mmj, cj, Tl);
             else           val = EXACT ? delta_love_ref(wl, LS, S, mmj, cj, Tl) : delta_love<CERT>(wl, LS, S, mmj, cj, Tl, phj, kcj, kuncj, coarse,
 #ifdef SD_AMBIG
                                                                                                       &vmag
@@ -1315,7 +1328,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         // the values of the team's first two lanes: the two ellipticity recursions, and NEVILL's del3 (every lane of the team
         // evaluated the same c3) - only where some team of the wavefront needs them
         float v0 = 0.0f, v1 = 0.0f;
-        if (__any(want_ratio || st == ST_NEVILL)) { v0 = __shfl(val, tbase); v1 = __shfl(val, (G > 1) ? tbase + 1 : tbase); }
+        if (__any(want_ratio || st == ST_NEVILL || st == ST_NEVILL0)) { v0 = __shfl(val, tbase); v1 = __shfl(val, (G > 1) ? tbase + 1 : tbase); }
         // what only a REFINE pass reads (wavefront-uniform test: in lock step most passes have no refining team):
         // the right neighbour of the crossing lane, the lane before the last one, and - the fourth point of the second
         // three-point estimate - two lanes below / above the crossing lane and two before the last one
@@ -1384,7 +1397,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         } else if (st == ST_SCAN) {
             ++passes;
             if (fl >= 0 && e_cross) {                          // bracket found -> refine
-                p0c = e_pc; p0d = e_pd; cb = e_c; db = e_d; mm_frozen = e_mm;
+                p0c = e_pc; p0d = e_pd; cb = e_c; db = e_d; mm_frozen = e_mm; p0mm = e_pmm;
                 // the low end was evaluated with ITS OWN layer dropping (idrop=0 per scan trial); if
                 // that differs from the frozen one its magnitude belongs to a different function
                 // and only its sign may be used (NEVILL's 10x guard, surfa.f:47-51, covers this)
@@ -1407,7 +1420,8 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
 #endif   // NEVILL's prologue, surfa.f:12-16 (del1 is the scan's value, whatever layer dropping it was computed with - as in the reference)
                     nv_ic = 0; nv_nev = 1; nv_m = 1;
                     croot = (p0c + cb) / 2.0f;                 // c3, evaluated by the next pass
-                    st = ST_NEVILL;
+                    st = (KIND == 1 && !EXACT) ? ST_NEVILL0 : ST_NEVILL;   // (Love: first the end values in the reference's arithmetic)
+                    sub = 0;
                     if (!EXACT && j == 0 && A.amb_count) atomicAdd(A.amb_count, 1);     // (statistics)
                 }
             } else if (fl >= 0) {
@@ -1431,7 +1445,11 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             // 1.71e-5 / 1.36e-5, profiles/r03a/ab_multi_defer.txt.)
             nv_ic = 0; nv_nev = 1; nv_m = 1;
             croot = (p0c + cb) / 2.0f;
-            st = ST_NEVILL;
+            st = (KIND == 1) ? ST_NEVILL0 : ST_NEVILL;
+            sub = 0;
+        } else if (st == ST_NEVILL0) {
+            if (G == 1) { if (sub == 0) { p0d = val; sub = 1; } else { db = val; st = ST_NEVILL; } }
+            else { p0d = v0; db = v1; st = ST_NEVILL; }
         } else if (st == ST_NEVILL) {
             // NEVILL, statement by statement (surfa.f:17-83).  One evaluation per pass: del3 = Delta(c3) has just
             // been computed by every lane of the team (v0); what follows runs up to the next evaluation.
@@ -1627,7 +1645,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             // waiting team evaluates nothing; each team's own sequence of evaluations - and so every result - is unchanged.
             if (solved) { st = ST_WEND; solved = false; }
             if (!__any(st == ST_SCAN) && st == ST_WREF) st = ST_REFINE;
-            if (!__any(st == ST_SCAN || st == ST_WREF || st == ST_REFINE || st == ST_NEVILL || st == ST_ELLIP) && st == ST_WEND)
+            if (!__any(st == ST_SCAN || st == ST_WREF || st == ST_REFINE || st == ST_NEVILL || st == ST_NEVILL0 || st == ST_ELLIP) && st == ST_WEND)
                 solved = true;
         }
 #ifdef SD_WAVECLOCK

@@ -46,16 +46,13 @@ __device__ __forceinline__ void closed_forms(int kind, double vs, double &vp, do
     }
 }
 
-__global__ __launch_bounds__(256) void surfdisp_layers_kernel(LayersArgs A)
+// the seismic properties of grid point g of chain c (Model1D.seisPropGrids' points: every input layer's N + 1 points, then
+// the 21 of the ReferenceMantle) - shared by the stack kernel and the prior kernel
+__device__ __forceinline__ GridVal grid_value(const LayersArgs &A, const int c, const int g)
 {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int L = A.idesc[2];
-    if (idx >= (long)A.C * L) return;
-    const int c = (int)(idx / L), i = (int)(idx % L);
-    const int nin = A.idesc[0], ngrid = A.idesc[1], has_ref = A.idesc[3];
+    const int nin = A.idesc[0], ngrid = A.idesc[1];
     const int *lay_i = A.idesc + 4;                    // 8 ints per input layer
     const int *coef_i = lay_i + 8 * nin;               // 8 slots per input layer
-    const int *top_i = coef_i + 8 * nin;               // L ints
     const double *lay_f = A.fdesc + 1;                 // 9 doubles per input layer
     const double *grid_f = lay_f + 9 * nin;            // 9 doubles per grid point
     const double *p = A.params + (size_t)c * A.N;
@@ -79,67 +76,73 @@ __global__ __launch_bounds__(256) void surfdisp_layers_kernel(LayersArgs A)
         }
         return z;
     };
-
-    auto grid_val = [&](int g) -> GridVal {
-        GridVal v;
-        if (g < ngrid) {
-            int l = 0;
-            while (l + 1 < nin && g >= lay_i[8 * l + 5]) ++l;
-            const double *gf = grid_f + 9 * g;
-            double zt, Hq;
-            (void)layer_span(l, zt, Hq);
-            v.z = zt + gf[0] * Hq;
-            double vs = 0.0;
-            const int kind = lay_i[8 * l];
-            if (kind == 6) {
-                const double *sc = A.scratch + ((size_t)c * 64 + (g - lay_i[8 * l + 4])) * 2;
-                vs = sc[0]; v.qs = sc[1];
-            } else if (kind == 7) {
-                const double H = Hq;
-                vs = (0.02 * (H * H) + 1.27 * H + 0.29 * 0.1) / (H + 0.29);
-            } else {
-                const int nc = lay_i[8 * l + 3];
-                for (int k = 0; k < nc; ++k) {
-                    const int sl = coef_i[8 * l + k];
-                    vs += gf[1 + k] * ((sl >= 0) ? p[sl] : lay_f[9 * l + 1 + k]);
-                }
-            }
-            v.vs = vs;
-            closed_forms(kind, vs, v.vp, v.rho, v.qs);
+    GridVal v;
+    if (g < ngrid) {
+        int l = 0;
+        while (l + 1 < nin && g >= lay_i[8 * l + 5]) ++l;
+        const double *gf = grid_f + 9 * g;
+        double zt, Hq;
+        (void)layer_span(l, zt, Hq);
+        v.z = zt + gf[0] * Hq;
+        double vs = 0.0;
+        const int kind = lay_i[8 * l];
+        if (kind == 6) {
+            const double *sc = A.scratch + ((size_t)c * 64 + (g - lay_i[8 * l + 4])) * 2;
+            vs = sc[0]; v.qs = sc[1];
+        } else if (kind == 7) {
+            const double H = Hq;
+            vs = (0.02 * (H * H) + 1.27 * H + 0.29 * 0.1) / (H + 0.29);
         } else {
-            // ReferenceMantle (layers.py:267-284): 21 points over 300 km hanging off the last grid point
-            const int gl = ngrid - 1;
-            int l = nin - 1;
-            const double *gf = grid_f + 9 * gl;
-            double zt, Hq;
-            const double zref = layer_span(l, zt, Hq);    // top of the ReferenceMantle
-            double vs0 = 0.0, vp0, rho0, qs0 = 0.0;
-            if (lay_i[8 * l] == 6) {
-                const double *sc = A.scratch + ((size_t)c * 64 + (gl - lay_i[8 * l + 4])) * 2;
-                vs0 = sc[0]; qs0 = sc[1];
-            } else if (lay_i[8 * l] == 7) {
-                vs0 = (0.02 * (Hq * Hq) + 1.27 * Hq + 0.29 * 0.1) / (Hq + 0.29);
-            } else {
-                const int nc = lay_i[8 * l + 3];
-                for (int k = 0; k < nc; ++k) {
-                    const int sl = coef_i[8 * l + k];
-                    vs0 += gf[1 + k] * ((sl >= 0) ? p[sl] : lay_f[9 * l + 1 + k]);
-                }
+            const int nc = lay_i[8 * l + 3];
+            for (int k = 0; k < nc; ++k) {
+                const int sl = coef_i[8 * l + k];
+                vs += gf[1 + k] * ((sl >= 0) ? p[sl] : lay_f[9 * l + 1 + k]);
             }
-            closed_forms(lay_i[8 * l], vs0, vp0, rho0, qs0);
-            const double t = (double)(g - ngrid) / 20.0;
-            const double zr = t * 300.0;
-            v.z = zref + zr;
-            v.vs = vs0 + zr * (0.35 / 200);
-            v.vp = vp0 + (v.vs * 1.76 - vs0 * 1.76);
-            v.rho = rho0 + ((3.4268 + (v.vs - 4.5) / 4.5) - (3.4268 + (vs0 - 4.5) / 4.5));
-            v.qs = qs0;
         }
-        return v;
-    };
-    (void)has_ref;
+        v.vs = vs;
+        closed_forms(kind, vs, v.vp, v.rho, v.qs);
+    } else {
+        // ReferenceMantle (layers.py:267-284): 21 points over 300 km hanging off the last grid point
+        const int gl = ngrid - 1;
+        int l = nin - 1;
+        const double *gf = grid_f + 9 * gl;
+        double zt, Hq;
+        const double zref = layer_span(l, zt, Hq);    // top of the ReferenceMantle
+        double vs0 = 0.0, vp0, rho0, qs0 = 0.0;
+        if (lay_i[8 * l] == 6) {
+            const double *sc = A.scratch + ((size_t)c * 64 + (gl - lay_i[8 * l + 4])) * 2;
+            vs0 = sc[0]; qs0 = sc[1];
+        } else if (lay_i[8 * l] == 7) {
+            vs0 = (0.02 * (Hq * Hq) + 1.27 * Hq + 0.29 * 0.1) / (Hq + 0.29);
+        } else {
+            const int nc = lay_i[8 * l + 3];
+            for (int k = 0; k < nc; ++k) {
+                const int sl = coef_i[8 * l + k];
+                vs0 += gf[1 + k] * ((sl >= 0) ? p[sl] : lay_f[9 * l + 1 + k]);
+            }
+        }
+        closed_forms(lay_i[8 * l], vs0, vp0, rho0, qs0);
+        const double t = (double)(g - ngrid) / 20.0;
+        const double zr = t * 300.0;
+        v.z = zref + zr;
+        v.vs = vs0 + zr * (0.35 / 200);
+        v.vp = vp0 + (v.vs * 1.76 - vs0 * 1.76);
+        v.rho = rho0 + ((3.4268 + (v.vs - 4.5) / 4.5) - (3.4268 + (vs0 - 4.5) / 4.5));
+        v.qs = qs0;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void surfdisp_layers_kernel(LayersArgs A)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int L = A.idesc[2];
+    if (idx >= (long)A.C * L) return;
+    const int c = (int)(idx / L), i = (int)(idx % L);
+    const int nin = A.idesc[0];
+    const int *top_i = A.idesc + 4 + 16 * nin;          // L ints behind the 8 + 8 ints per input layer
     const int g = top_i[i];
-    const GridVal a = grid_val(g), b = grid_val(g + 1);
+    const GridVal a = grid_value(A, c, g), b = grid_value(A, c, g + 1);
     float *m = A.model + (size_t)c * 5 * L;            // rows vp, vs, rho, h, 1/Qs (fast_surf.f:2-5)
     const double qs = (a.qs + b.qs) / 2;
     m[0 * L + i] = (float)((a.vp + b.vp) / 2);
@@ -147,6 +150,53 @@ __global__ __launch_bounds__(256) void surfdisp_layers_kernel(LayersArgs A)
     m[2 * L + i] = (float)((a.rho + b.rho) / 2);
     m[3 * L + i] = (float)(b.z - a.z);
     m[4 * L + i] = (float)(qs > 0 ? 1.0 / qs : 0.0);
+}
+
+// The GENERIC prior predicates of the reference's model classes (models.py:294-320 and alike: what every `isgood` there is
+// built from) on the grid points of Model1D.seisPropGrids, one thread per (chain, output layer) - so that a sampler with a
+// prior keeps its lock step on the device (MetropolisBatch, pysurfinv_amd.mcmc.PriorRules):
+//   flags[i] bit 0: Vs must INCREASE across output layer i (bottom point - top point >= eps: monoIncrease, models.py:8-9,
+//                   over the grid points of a group);
+//            bit 1: ... and from its bottom point to the top point of output layer i + 1 (two input layers of one such group);
+//            bit 2: Vs must not DROP from its bottom point to the top point of output layer i + 1 ("Vs jump between group is
+//                   positive", models.py:302-307);
+//            bit 3: the cap applies to its two points: Vs <= vs_max (models.py:309-313; not the ReferenceMantle's layers).
+// tags [C]: a chain whose model breaks a rule gets tags[c] = mark_tag; only_tag >= 0: only the chains with tags[c] == only_tag are
+// looked at (the ones the last masked redraw touched) - rounds of a step use rising tags, so nothing is cleared in between.
+__global__ __launch_bounds__(256) void surfdisp_prior_kernel(LayersArgs A, const int *flags, double vs_max, int only_tag, int mark_tag,
+                                                             unsigned char *tags)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int L = A.idesc[2];
+    if (idx >= (long)A.C * L) return;
+    const int c = (int)(idx / L), i = (int)(idx % L);
+    // (a chain found bad by another of its threads already carries mark_tag > only_tag: still looked at, the outcome is the same)
+    if (only_tag >= 0 && tags[c] < (unsigned char)only_tag) return;
+    const int f = flags[i];
+    if (f == 0) return;
+    const int nin = A.idesc[0];
+    const int *top_i = A.idesc + 4 + 16 * nin;
+    const int g = top_i[i];
+    const GridVal a = grid_value(A, c, g), b = grid_value(A, c, g + 1);
+    const double eps = 2.220446049250313e-16;              // np.finfo(float).eps, models.py:8
+    bool ok = true;
+    if (f & 8) ok = ok && !(a.vs > vs_max) && !(b.vs > vs_max);
+    if (f & 1) ok = ok && (b.vs - a.vs >= eps);
+    if ((f & 6) && i + 1 < L) {
+        const GridVal n = grid_value(A, c, top_i[i + 1]);
+        if (f & 2) ok = ok && (n.vs - b.vs >= eps);
+        if (f & 4) ok = ok && !(n.vs < b.vs);
+    }
+    if (!ok) tags[c] = (unsigned char)mark_tag;
+}
+
+hipError_t launch_prior(hipStream_t s, const LayersArgs &a, int L, const int *flags, double vs_max, int only_tag, int mark_tag,
+                        unsigned char *tags)
+{
+    const long total = (long)a.C * L;
+    const int grid = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(surfdisp_prior_kernel, dim3(grid), dim3(256), 0, s, a, flags, vs_max, only_tag, mark_tag, tags);
+    return hipGetLastError();
 }
 
 hipError_t launch_layers(hipStream_t s, const LayersArgs &a, int L)

@@ -72,6 +72,14 @@ __global__ __launch_bounds__(256) void surfdisp_mcmc_propose_kernel(McmcProposeA
     const double lo = A.vmin[n], hi = A.vmax[n], s = A.step[n];
     const uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
     const long gidx = idx + A.chain0 * A.N;                             // (chain, parameter) of the whole sampler: the random stream's index
+    if (A.redo) {
+        // masked redraw (a sampler with prior rules, MetropolisBatch): only the chains whose last proposal broke a rule draw
+        // again - try number A.attempt of this step (its own random numbers); reset 2: the chain's state itself (no proposal)
+        if (A.redo[c] != (unsigned char)A.redo_tag) return;
+        A.out[idx] = (A.reset == 2) ? A.p[idx]
+                                    : draw_bounded(A.p[idx], lo, hi, s, k0, k1, A.counter, 64u + (uint32_t)A.attempt, gidx, A.reset != 0);
+        return;
+    }
     const int M = A.depth > 1 ? (1 << A.depth) - 1 : 1;
     double S[SD_MCMC_MAX_NODES];
     S[0] = A.p[idx];

@@ -139,6 +139,8 @@ class BatchPlan:
                 rc = _lib.lib().surfdisp_forward_batch_device_timed(*args, ms)
                 _lib.check(rc)
                 return self.c, self.u, self.status, tuple(float(x) for x in ms)
+            if want_ratio and events is not None:
+                raise ValueError("BatchPlan.run: want_ratio and events cannot be combined (no events variant of surfdisp_forward_batch_device2)")
             if want_ratio:
                 # ABI 3: also the Rayleigh ellipticity (the reference's COMMON /o/ ratio, calcul.f:195) -> self.ratio [B, P]
                 if getattr(self, "ratio", None) is None:

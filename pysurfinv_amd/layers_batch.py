@@ -306,8 +306,11 @@ class Model1DBatch:
         if self._aux is None:
             raise ValueError(f"this model has per-point constants {self.aux_names}: call set_local_info(table) first")
         if rows is None:
-            if params.shape[0] == 1 and self._aux.shape[0] >= 1:
+            if params.shape[0] == 1 and self._aux.shape[0] == 1:
                 aux = self._aux[:1]
+            elif params.shape[0] == 1:
+                # (r03 took row 0 silently: a single-model call on a per-point model got point 0's topo / lithoAge / period)
+                raise ValueError(f"one parameter vector against {self._aux.shape[0]} rows of local info: pass rows=[i]")
             elif params.shape[0] != self._aux.shape[0]:
                 raise ValueError(f"{params.shape[0]} parameter vectors against {self._aux.shape[0]} rows of local info: pass rows=")
             else:
@@ -681,6 +684,51 @@ class Model1DBatch:
         self._native_desc = (torch.tensor(idesc, dtype=torch.int32, device=self.device),
                              torch.tensor(fdesc, dtype=torch.float64, device=self.device), L)
         return self._native_desc
+
+    def prior_flags(self, rules):
+        """int32 [L] flags of csrc/surfdisp_layers.hip::surfdisp_prior_kernel for a ``PriorRules`` (per OUTPUT layer of the
+        native descriptor: bit 0 Vs increases across the layer, bit 1 ... and on to the next layer's top, bit 2 Vs does not
+        drop to the next layer's top, bit 3 the Vs cap applies), or None when the model has no native descriptor / a thermal layer."""
+        desc = self.native_descriptor()
+        if desc is None or self._native_thermal:
+            return None
+        flags = []
+        groups = [self.GROUP[l["kind"]] for l in self.layers]
+        for l, (lay, N) in enumerate(zip(self.layers, self._static_sig)):
+            mono = groups[l] in rules.monotone_groups
+            for q in range(N):                                    # the N output layers of input layer l
+                f = (1 if mono else 0) | (8 if rules.vs_max is not None else 0)
+                if q == N - 1 and l + 1 < len(self.layers):
+                    if groups[l + 1] == groups[l]:
+                        f |= 2 if mono else 0
+                    elif rules.positive_jumps:
+                        f |= 4
+                flags.append(f)
+        flags += [0] * (desc[2] - len(flags))                   # (the ReferenceMantle's layers carry no rule)
+        return self.torch.tensor(flags, dtype=self.torch.int32, device=self.device)
+
+    def prior_good(self, params, rules, rows=None):
+        """bool [B]: ``rules`` evaluated in torch on ``seis_prop_grids`` - the reference's own formulation (models.py:294-320:
+        tests on the grid points' Vs and group names); what the device kernel is checked against."""
+        torch = self.torch
+        (z, vs, vp, rho, qs, qp), grp, ngrid = self.seis_prop_grids(params, rows=rows, ref_layer=False)
+        if not bool((grp == grp[:1]).all()):
+            raise NotImplementedError("prior_good: every row must have the same layer structure")
+        nm = np.asarray([self.GROUP_NAMES[int(q)] for q in grp[0].tolist() if int(q) >= 0])
+        vs = vs[:, :nm.size]
+        ok = torch.ones(vs.shape[0], dtype=torch.bool, device=vs.device)
+        eps = float(np.finfo(float).eps)
+        if rules.positive_jumps:                                   # models.py:302-307
+            for i in np.where(nm[1:] != nm[:-1])[0]:
+                ok &= ~(vs[:, i + 1] < vs[:, i])
+        if rules.vs_max is not None:                               # models.py:309-313
+            ok &= ~(vs > rules.vs_max).any(dim=1)
+        for g in rules.monotone_groups:                            # models.py:315-320 (monoIncrease, :8-9)
+            sel = torch.as_tensor(np.where(nm == g)[0], device=vs.device)
+            if sel.numel() > 1:
+                v = vs[:, sel]
+                ok &= (v[:, 1:] - v[:, :-1] >= eps).all(dim=1)
+        return ok
 
     def to_model_native(self, params, rows=None):
         """``to_model`` through the HIP kernel surfdisp_layers_kernel (one launch, graph-capturable)."""

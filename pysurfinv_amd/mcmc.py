@@ -34,6 +34,41 @@ from .brownian import ParamSpec, TorchProposer
 FAIL = 88888.0                                                  # point.py:21
 
 
+class PriorRules:
+    """The GENERIC prior predicates the reference's model classes build ``isgood`` from (models.py:294-320), in a form the
+    device can evaluate (csrc/surfdisp_layers.hip::surfdisp_prior_kernel) - pass it as ``MetropolisBatch(isgood=...)`` and
+    the lock step stays on the device (fused kernels, chain groups, HIP graphs):
+
+    * ``monotone_groups``: Vs must increase with depth over the grid points of these layer groups ("sediment", "crust", ...:
+      ``monoIncrease``, models.py:8-9, 315-320);
+    * ``positive_jumps``: Vs must not drop across a boundary between two groups (models.py:302-307);
+    * ``vs_max``: every grid point's Vs at most this (models.py:309-313; None: no cap).
+
+    The reference redraws the WHOLE proposal until the predicate holds (``MCinv.perturb``: 1000 tries, then ``reset``'s uniform
+    draws, models.py:192-219).  On the device the same loop runs as MASKED redraw rounds without a host synchronisation:
+    ``rounds`` Gaussian rounds (only the chains whose proposal broke a rule draw again), then ``reset_rounds`` rounds of uniform
+    prior draws, and a chain that is still without a good proposal proposes its own state (a wasted step: with a prior that
+    accepts half of the Gaussian draws, 1 chain in 60 reaches the uniform rounds and fewer than 1 in 1e3 the wasted step).  Called with a parameter tensor it evaluates
+    the same rules in torch on ``Model1DBatch.seis_prop_grids`` (the torch lock step; the tests compare the two)."""
+
+    def __init__(self, model, monotone_groups=("sediment", "crust"), positive_jumps=True, vs_max=None, rounds=5, reset_rounds=2):
+        self.model = model
+        self.monotone_groups = tuple(monotone_groups)
+        self.positive_jumps = bool(positive_jumps)
+        self.vs_max = None if vs_max is None else float(vs_max)
+        self.rounds, self.reset_rounds = int(rounds), int(reset_rounds)
+        self._flags = None
+
+    def __call__(self, params, rows=None):
+        return self.model.prior_good(params, self, rows=rows)
+
+    def device_flags(self):
+        """int32 [L] flags for the prior kernel, or None (no native descriptor / thermal layer: the torch loop serves)."""
+        if self._flags is None:
+            self._flags = self.model.prior_flags(self)
+        return self._flags
+
+
 class ChainGroups:
     """The chains of a ``MetropolisBatch`` as contiguous groups, each advancing on its own stream (``chain_groups``).
     ``fork()`` once (the group streams wait for the current stream), ``step()`` per lock step, ``join()`` once (the current
@@ -60,7 +95,27 @@ class ChainGroups:
             ch._pipelined = True                                # the library sizes its teams for both groups' stacks
             self.children.append(ch)
 
+    def _refresh(self):
+        """The children's slices of the parent's observations / local rows and its run-time switches, taken afresh at every
+        fork: a parent whose observations or ``local_rows`` were replaced, or whose ``independent`` / ``fast_scan`` changed after
+        a first grouped run, must not advance on the first run's copies."""
+        mc = self.mc
+        for g, ch in enumerate(self.children):
+            lo, hi = self.bounds[g], self.bounds[g + 1]
+            if mc.c_obs.ndim == 2:
+                if mc.c_obs.shape[0] != self.C:
+                    raise ValueError(f"{self.C} chains against {mc.c_obs.shape[0]} rows of observations")
+                ch.c_obs, ch.uncer, ch.mask = mc.c_obs[lo:hi], mc.uncer[lo:hi], mc.mask[lo:hi]
+            else:
+                ch.c_obs, ch.uncer, ch.mask = mc.c_obs, mc.uncer, mc.mask
+            ch.local_rows = None if mc.local_rows is None else mc.local_rows[lo:hi]
+            ch.independent, ch.fast_scan, ch.isgood = mc.independent, mc.fast_scan, mc.isgood
+            ch._chain0 = mc._chain0 + lo
+            if ch._fz is not None and (ch._fz["c_obs"].data_ptr() != ch.c_obs.contiguous().data_ptr()):
+                ch._fz = None                                   # (the fused buffers hold contiguous copies of the observations)
+
     def fork(self):
+        self._refresh()
         cur = self.mc.torch.cuda.current_stream(self.mc.device)
         for s in self.streams:
             s.wait_stream(cur)
@@ -191,8 +246,11 @@ class MetropolisBatch:
     # ------------------------------------------------------------------ fused device path (csrc/surfdisp_mcmc.hip)
     def fused_available(self):
         """The lock step can run as propose kernel -> stacks -> solver -> accept kernel (no torch glue, no host
-        synchronisation): device proposer, no ``isgood`` callback, the HIP forward path."""
-        return (self.isgood is None and isinstance(self.proposer, TorchProposer) and self.device.type == "cuda"
+        synchronisation): device proposer, the HIP forward path, and no ``isgood`` callback - or a ``PriorRules`` one, whose
+        redraw loop runs on the device too (``_propose_with_rules``)."""
+        dev_prior = self.isgood is None or (isinstance(self.isgood, PriorRules) and self.device.type == "cuda"
+                                            and self.local_rows is None and self.isgood.device_flags() is not None)
+        return (dev_prior and isinstance(self.proposer, TorchProposer) and self.device.type == "cuda"
                 and self._forward is None)
 
     def _fused_buffers(self, C):
@@ -261,6 +319,8 @@ class MetropolisBatch:
                 p1 = st["p1"]
                 _lib.check(L.surfdisp_mcmc_propose_device(stream, C, N, ptr(p), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step),
                                                           pr.seed_int, counter, 0, ptr(p1), self._chain0))
+                if self.isgood is not None:
+                    self._redraw_with_rules(p, p1, counter, stream)
             c, status = self._solve_raw(p1)
             _lib.check(L.surfdisp_mcmc_accept_device(stream, C, N, int(self.periods.numel()), ptr(c), ptr(status),
                                                      ptr(st["c_obs"]), ptr(st["uncer"]), ptr(st["mask8"]),
@@ -268,6 +328,39 @@ class MetropolisBatch:
                                                      rowp, int(row_stride), pr.seed_int, counter, 1 if first else 0,
                                                      self._chain0))
         return p
+
+    def _redraw_with_rules(self, p, p1, counter, stream):
+        """The redraw loop of ``MCinv.perturb`` / ``reset`` (models.py:192-219) for a ``PriorRules`` predicate, on the device and
+        without a host synchronisation: the prior kernel marks the chains whose proposal ``p1`` breaks a rule, the masked
+        proposal kernel draws those again - ``rounds`` Gaussian rounds, ``reset_rounds`` uniform ones, then the chain's own
+        state.  One tag per chain, rising from round to round (cleared once per step)."""
+        import ctypes
+        torch = self.torch
+        rules = self.isgood
+        C, N = p1.shape
+        mb = rules.model
+        idesc, fdesc, Lout = mb.native_descriptor()
+        flags = rules.device_flags()
+        st = self._fz
+        if st.get("tags") is None or st["tags"].numel() != C:
+            st["tags"] = torch.zeros(C, dtype=torch.uint8, device=self.device)
+        tags = st["tags"]
+        L = _lib.lib()
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+        pr = self.proposer
+        vmax = -1.0 if rules.vs_max is None else rules.vs_max
+        pfull = lambda q: q if mb.n_aux == 0 else mb._full(q).contiguous()
+        total = rules.rounds + rules.reset_rounds + 1
+        tags.zero_()                                               # once per step: the rounds use rising tags 1, 2, ...
+        for r in range(total):
+            q = pfull(p1)
+            # round r: chains redrawn in round r - 1 carry tag r (all chains in round 0); the ones that break a rule get r + 1 ...
+            _lib.check(L.surfdisp_prior_device(stream, C, q.shape[1], int(Lout), ptr(q), ptr(idesc), ptr(fdesc), ptr(flags),
+                                               ctypes.c_double(vmax), r if r > 0 else -1, r + 1, ptr(tags)))
+            # ... and draw again: Gaussian rounds, then uniform prior draws, last the chain's own state
+            mode = 0 if r < rules.rounds else (1 if r < rules.rounds + rules.reset_rounds else 2)
+            _lib.check(L.surfdisp_mcmc_propose_masked_device(stream, C, N, ptr(p), ptr(pr.vmin), ptr(pr.vmax), ptr(pr.step),
+                                                             pr.seed_int, counter, r, mode, ptr(tags), r + 1, ptr(p1), self._chain0))
 
     SPEC_MAX_STACKS = 2048          # stacks per speculative lock step: a 64-lane team = one wavefront each, the chip holds 4 096
 
@@ -280,6 +373,8 @@ class MetropolisBatch:
         instead (``independent``: 0.24 ms per step plain, 0.29 with d = 3)."""
         if self.independent is True or (self.independent == "auto" and C < self.AUTO_INDEP_CHAINS):
             return 1
+        if self.isgood is not None:
+            return 1                                               # (prior rules: the redraw rounds belong to the plain lock step)
         for d in (4, 3, 2):
             if C * ((1 << d) - 1) <= self.SPEC_MAX_STACKS:
                 return d
@@ -412,10 +507,12 @@ class MetropolisBatch:
             fused = self.fused_available()
         fused = bool(fused) and not priori                         # a priori run evaluates nothing: the torch loop below
         if fused and not self.fused_available():
-            raise ValueError("fused=True needs the device proposer, no isgood callback and the HIP forward path")
+            raise ValueError("fused=True needs the device proposer, no isgood callback (or a PriorRules one) and the HIP forward path")
         if spec_depth is None:
             spec_depth = self.auto_spec_depth(C) if (fused and groups in (None, 1)) else 1
         spec_depth = int(spec_depth)
+        if spec_depth > 1 and groups not in (None, 1):
+            raise ValueError("run: chain groups and speculative lock steps (spec_depth > 1) cannot be combined")
         if spec_depth > 1 and not priori and not fused:
             return self._run_speculative(n_chains, chainL, init_first, _init_mask, spec_depth)
         track = torch.zeros((C, chainL, 3 + N), dtype=torch.float64, device=self.device)
@@ -591,8 +688,10 @@ class MetropolisBatch:
         for all practical purposes.  Random numbers come from torch's default device generator
         (graph-safe Philox)."""
         torch = self.torch
-        if self.isgood is not None or not isinstance(self.proposer, TorchProposer) or self._forward is not None:
-            raise ValueError("run_graphed needs the device proposer, no isgood callback and the HIP forward path")
+        if self.isgood is not None or not self.fused_available():
+            # (the captured step is torch glue with torch's graph-safe generator - the fused kernels take their Philox counter by
+            # value, which a graph would freeze -, and that glue has no redraw loop: no predicate here, PriorRules or callback)
+            raise ValueError("run_graphed needs the device proposer, no isgood predicate and the HIP forward path")
         C, N = int(n_chains), self.spec.n
         dev = self.device
         pr = self.proposer
