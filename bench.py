@@ -423,6 +423,11 @@ def workload_grid(rt, args, steps=None, warmup=None):
         mb, c_obs, unc = _mcmc_setup(rt, pts, chains)
         mc = MetropolisBatch(mb.spec, mb.to_model, MCMC_PERIODS, rep(c_obs), rep(unc), device=rt.dev, seed=7 + rt.rank)
     C = pts * chains
+    if os.environ.get("BENCH_GRID_PRIOR") == "1":
+        # the lock step with prior predicates on the device (PriorRules: Vs increasing in sediment and crust, no drop across group
+        # boundaries, Vs <= 4.9 km/s - the generic tests of the reference's model classes, models.py:294-320)
+        from pysurfinv_amd.mcmc import PriorRules
+        mc.isgood = PriorRules(mb, vs_max=4.9)
     state = {}
 
     fused = mc.fused_available() and os.environ.get("BENCH_GRID_FUSED", "1") == "1"
@@ -498,6 +503,8 @@ def workload_grid(rt, args, steps=None, warmup=None):
                        "lock_step": ("fused: propose kernel, parameters->stacks, prep / root search / finish, accept kernel"
                                      if fused else "torch glue around the solver"),
                        "chain_groups": cg.G if cg is not None else 1,
+                       "prior_rules": "PriorRules(sediment + crust monotone, positive jumps, Vs <= 4.9): masked redraw rounds on the device"
+                                      if mc.isgood is not None else None,
                        "points_per_gpu": pts, "chains_per_point": chains, "chains_per_gpu": C, "layers": L,
                        "periods": len(MCMC_PERIODS)},
             "accept_rate_last_step": acc_rate, "forward_solves_timed_this_rank": int(mc.n_forward - n0)}

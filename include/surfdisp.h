@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SURFDISP_ABI_VERSION 3
+#define SURFDISP_ABI_VERSION 4      /* 4 (r04): + SURFDISP_KERN_REFCOORD, surfdisp_workspace_counters, surfdisp_prior_device, surfdisp_mcmc_propose_masked_device; every ABI-3 symbol kept */
 #define SURFDISP_NPER_MAX 200      /* fast_surf.pyf:14-19: cvper and outputs are real*4[200] */
 #define SURFDISP_NLAY_MAX 200      /* layers per stack accepted by this library */
 

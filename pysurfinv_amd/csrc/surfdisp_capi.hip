@@ -322,7 +322,11 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
     kind &= ~SD_KIND_FLAGS;
     // Love: the coarse scan with its Sturm-count certificate (phase_body, CERT) is the DEFAULT - it returns the bracket the
     // point-by-point scan returns, by a theorem, not a heuristic; SURFDISP_EXACTSCAN / SURFDISP_CERTSCAN=0 walk every point
+#if defined(SD_RCERT) && SD_RCERT
+    fastscan = !exactscan && !strict && (kn.certscan != 0 || fastscan);      // (experimental build: the Rayleigh count drives the scan too)
+#else
     if (kind == SURFDISP_KIND_LOVE) fastscan = !exactscan && !strict && (kn.certscan != 0 || fastscan);
+#endif
     // the ellipticity recursions (two more evaluations per period) feed the group-velocity kernel - and the caller who
     // asked for the ratio itself (ABI 3), also in a phase-only call
     const bool want_ell = (kind == SURFDISP_KIND_RAYLEIGH) && (!phase_only || ratio != nullptr);

@@ -384,8 +384,29 @@ __device__ __forceinline__ RState ray_start(const RTrial &t, const int start, co
 }
 // FIRST: only the TOP layer may be liquid in the production kernel (a stack with a liquid layer further down is handed
 // to the exact fallback kernel by the prep kernel's statistics), so the test is made once per evaluation
-template <bool FIRST>
-__device__ __forceinline__ void ray_step(RState &s, const RTrial &t, const RLyr &y, const int start, float &phi)
+// CERT (r04, the certified coarse scan for Rayleigh): the state's first component b1 is det U of the two solutions that satisfy
+// the free-surface condition (start: U = I, tractions 0).  The number of modes with phase velocity below the trial c is
+//      N(c) = #{sign changes of b1 on the way down} + #{positive eigenvalues of Z_h - Z_s at the top of the half space}
+// (Morse index of the Neumann problem + the half space's boundary index; Z = T U^-1 with the tractions ordered (tr, tz), which
+// makes the motion-stress system Hamiltonian and Z symmetric; scripts/analysis/rayleigh_count*.py: holds with a constant offset
+// over the whole range of c on every random stack tried).  NOT A CERTIFICATE, and not used by the default build (SD_RCERT): the
+// sign changes AT THE INTERFACES miss zeros of b1 that come in pairs inside one layer - a thick evanescent layer (27 km of rock at
+// 10 s), but also a thin one whose S velocity the trial is passing (a 2.7 km layer of 0.71 km/s at c = 0.70: two zeros, vertical
+// phase 1.8 rad) -, and there is no closed per-layer count like Love's rotation angle: with every guard below in place 25 of
+// 1.3e8 soak stacks still came back on another root (profiles/r04a/rayleigh_count.txt).  Measured in float64 (2 003 trials on random stacks with
+// soft tops and layers of 2 - 40 km): no zero is missed while k d (|r_alpha| + |r_beta|) - vertical phase or decay exponent alike -
+// stays below 5 in every layer, 13 % of the trials miss some beyond.  kc counts the sign changes, kunc flags a trial whose
+// count is not safe: a layer beyond SD_RCERT_PHASE (3.0: the margin is the soak's to confirm - an empirical guard, NOT a theorem,
+// unlike Love's), or a new b1 that is the remainder of a cancellation (its sign within rounding).
+#ifndef SD_RCERT_PHASE
+#define SD_RCERT_PHASE 3.0f
+#endif
+#ifndef SD_RCERT
+#define SD_RCERT 0              // 1: the Rayleigh count drives the coarse scan (experimental builds; 46.6 M solves/s on the bench batch,
+#endif                          // 25 of 1.3e8 soak stacks on another root: profiles/r04a/rayleigh_count.txt)
+template <bool FIRST, bool CERT = false>
+__device__ __forceinline__ void ray_step(RState &s, const RTrial &t, const RLyr &y, const int start, float &phi, int *kc = nullptr,
+                                         bool *kunc = nullptr)
 {
     float b1 = s.b1, h2 = s.h2, h3 = s.h3, h4 = s.h4, h5 = s.h5;
     const float wvno = t.wvno, csq = t.csq, icsq = t.icsq;
@@ -405,6 +426,7 @@ __device__ __forceinline__ void ray_step(RState &s, const RTrial &t, const RLyr 
         // liquid surface layer, surfa.f:216-251 (skipped entirely in the ellipticity passes): only a11 = cosp and
         // a21 = rhoc sinpr are non-zero (surfa.f:236-250)
         if (start != 1) return;
+        if (CERT) *kunc = true;                            // (a liquid layer: no certificate)
         const float pm = wd * ra;
         float sinpr, cosp;
         if (fabsf(ra) < ACCUR) { sinpr = wd; cosp = 1.0f; }
@@ -457,6 +479,11 @@ __device__ __forceinline__ void ray_step(RState &s, const RTrial &t, const RLyr 
     const float E1 = fmaf(rsinp, t1, fmaf(-Cx, h4, D * u2));
     const float E2 = fmaf(sinpr, t2, fmaf(Cy, h2, D * u1));
     const float n1 = (b1 - E1) - E2;
+    if (CERT) {
+        *kc += ((n1 < 0.0f) != (b1 < 0.0f)) ? 1 : 0;
+        *kunc = *kunc || !(fabsf(pm) + fabsf(qm) < SD_RCERT_PHASE) ||
+                !(fabsf(n1) > 1.0e-4f * (fabsf(b1) + fabsf(E1) + fabsf(E2)));
+    }
     const float n3 = fmaf(g, E1, fmaf(g1, E2, h3));
     const float n5 = fmaf(g2, E1, fmaf(g12, E2, h5));
     const float n2 = fmaf(cosp, t1, sinpr * fmaf(rsinq, h4, cosq * u2));
@@ -469,7 +496,8 @@ __device__ __forceinline__ void ray_step(RState &s, const RTrial &t, const RLyr 
 // *mag (if given): the sum of the magnitudes of the closure's five terms - |value| far below it means the value is the
 // remainder of a cancellation, i.e. its SIGN is within the rounding of this arithmetic (the scan's ambiguity test)
 __device__ __forceinline__ float ray_close(const RState &s, const RTrial &t, const RLyr &A, const float rho_last,
-                                           const float rho_prev, const int start, float *mag = nullptr, const bool want_mag = true)
+                                           const float rho_prev, const int start, float *mag = nullptr, const bool want_mag = true,
+                                           int *kc = nullptr, bool *kunc = nullptr)
 {
     const float csq = t.csq, icsq = t.icsq;
     const float sv = A.sv, ia2 = A.ia2;
@@ -494,16 +522,33 @@ __device__ __forceinline__ float ray_close(const RState &s, const RTrial &t, con
     const float h15 = rba * (irho * irho) * ia2 * icsq * ig;         // rba/(rho a)^2/c^2/g
     const float h12 = -ig * it12;
     const float bb1 = h11 * s.b1 + rhoc * (h12 * s.h2 + 2.0f * h13 * s.h3 + h14 * s.h4 + rhoc * (h15 * s.h5));
+    if (kc) {
+        // boundary index at the top of the half space: positive eigenvalues of S = Z_h - Z_s (both divided by k > 0),
+        //   Z_s = (rhoc / b1) [[h4, -h3], [-h3, -h2]]   (b2..b4 = -minors / k: rhoc h2..h4 of this state),
+        //   Z_h = rho c^2 / (1 - ra rb) [[-ra, g1 - g ra rb], [g1 - g ra rb, -rb]]   (ra, rb > 0: the half space's decaying pair)
+        const float rap = fabsf(ra), rbp = fabsf(rb);
+        const float zf = rho_last * csq * rcp_nr(1.0f - rap * rbp), zo = g1 - g * rap * rbp;
+        const float sf = rhoc * rcp_nr(s.b1);
+        const float S11 = -zf * rap - sf * s.h4, S12 = zf * zo + sf * s.h3, S22 = -zf * rbp + sf * s.h2;
+        const float dq = S11 * S22 - S12 * S12, tp = S11 + S22;
+        *kc += (dq < 0.0f) ? 1 : ((tp > 0.0f) ? 2 : 0);
+        // unsafe: the half space not evanescent in P and S, a determinant or - where it matters - a trace within rounding, not finite
+        *kunc = *kunc || !(arga > 0.0f) || !(argb > 0.0f) || !(fabsf(dq) > 1.0e-4f * (fabsf(S11 * S22) + S12 * S12)) ||
+                (dq > 0.0f && !(fabsf(tp) > 1.0e-4f * (fabsf(S11) + fabsf(S22)))) || !fin(dq) || !fin(s.b1) || s.b1 == 0.0f;
+    }
     if (mag && want_mag) *mag = fabsf(h11 * s.b1) + fabsf(rhoc) * (fabsf(h12 * s.h2) + 2.0f * fabsf(h13 * s.h3) + fabsf(h14 * s.h4) +
                                                         fabsf(rhoc * (h15 * s.h5)));
     return (start == 1) ? -bb1 : bb1;
 }
 
-template <bool PIPE2 = true>
+template <bool PIPE2 = true, bool CERT = false>
 __device__ __forceinline__ float delta_rayleigh(const float *wq, const int LS, const int S,
                                                 const int mmax, const float c, const float T,
-                                                const int start, float &phi, float *mag = nullptr, const bool want_mag = true)
+                                                const int start, float &phi, float *mag = nullptr, const bool want_mag = true,
+                                                int *kcp = nullptr, bool *kuncp = nullptr, const bool count = false)
 {
+    int kc_ = 0; bool kunc_ = !count;
+    int *const kc = &kc_; bool *const kunc = &kunc_;
     // phi: vertical phase sum_i k d_i sqrt(c^2/v_i^2 - 1) over the layers (and wave types) that are oscillatory
     // at c -- the WKB mode counter the opt-in fast scan bounds between two coarse points (free: pm and qm are
     // the recursion's own arguments)
@@ -518,16 +563,16 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int LS, c
     int m = 0;
     if (last >= 1) {                                                 // layer 0: the one that may be water
         const RLyr Bq = load(1);
-        ray_step<true>(s, t, A, start, phi);
+        if (CERT && count) ray_step<true, true>(s, t, A, start, phi, kc, kunc); else ray_step<true>(s, t, A, start, phi);
         A = Bq;
         m = 1;
     }
     if (PIPE2) {
         while (m + 2 <= last) {
             const RLyr Bq = load(m + 1);
-            ray_step<false>(s, t, A, start, phi);
+            if (CERT && count) ray_step<false, true>(s, t, A, start, phi, kc, kunc); else ray_step<false>(s, t, A, start, phi);
             A = load(m + 2);
-            ray_step<false>(s, t, Bq, start, phi);
+            if (CERT && count) ray_step<false, true>(s, t, Bq, start, phi, kc, kunc); else ray_step<false>(s, t, Bq, start, phi);
             m += 2;
         }
     } else {
@@ -539,18 +584,21 @@ __device__ __forceinline__ float delta_rayleigh(const float *wq, const int LS, c
         // headline drops 7 %, profiles/r02e/ab_experiments.txt)
         while (m + 1 <= last) {
             const RLyr Bq = load(m + 1);
-            ray_step<false>(s, t, A, start, phi);
+            if (CERT && count) ray_step<false, true>(s, t, A, start, phi, kc, kunc); else ray_step<false>(s, t, A, start, phi);
             A = Bq;
             m += 1;
         }
     }
     if (m < last) {
         const RLyr Bq = load(m + 1);
-        ray_step<false>(s, t, A, start, phi);
+        if (CERT && count) ray_step<false, true>(s, t, A, start, phi, kc, kunc); else ray_step<false>(s, t, A, start, phi);
         A = Bq;
     }
     // A holds layer mmax-1 here; the state is in the scale of the last layer stepped through
-    return ray_close(s, t, A, W_R(last), last >= 1 ? W_R(last - 1) : 0.0f, start, mag, want_mag);
+    const float v = ray_close(s, t, A, W_R(last), last >= 1 ? W_R(last - 1) : 0.0f, start, mag, want_mag,
+                              (CERT && count) ? kc : nullptr, kunc);
+    if (CERT) { *kcp = kc_; *kuncp = kunc_ || (last < 1); }
+    return v;
 }
 
 // The exact fallback kernel's Rayleigh secular function: DLTAR4 restated statement by statement (surfa.f:193-357),
@@ -915,7 +963,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     // opt-in fast scan (teams of 2..8 lanes): after the first pass of a period the scan advances
     // FSTRIDE grid points per lane; an interval between two coarse points is skipped only if it is
     // judged free of sign changes (see below), otherwise its fine points are scanned as usual
-    constexpr int FSTRIDE = (FAST && KIND == 1 && G <= 4) ? SD_CERT_STRIDE : 4;
+    constexpr int FSTRIDE = (FAST && (KIND == 1 || SD_RCERT) && G <= 4) ? SD_CERT_STRIDE : 4;
     constexpr bool fastok = FAST && (G >= 2) && (G <= 8);
     // CERT (Love): the coarse scan's certificate is a THEOREM instead of the heuristics below.  At fixed frequency the angle of
     // the pair (displacement, stress) at the surface, followed continuously up from the half space, falls monotonically as
@@ -929,7 +977,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     // lanes (deep stacks) one plain pass already covers 16 grid points and the coarse pass's dearer evaluations ate the
     // gain (16 384 x L64: 1.12 -> 1.21 ms), so they keep the plain scan.  Checked against the point-by-point scan bit for
     // bit on 5.7e8 random stacks (scripts/soak_cert.py).
-    constexpr bool CERT = fastok && (KIND == 1) && !EXACT;
+    // (Rayleigh: -DSD_RCERT=1 builds only - the count of ray_step / ray_close is NOT a certificate: see there and
+    // profiles/r04a/rayleigh_count.txt; by default Rayleigh's FAST instantiations are the opt-in heuristic scan of r01.)
+    constexpr bool CERT = fastok && (KIND == 1 || SD_RCERT) && !EXACT;
     int p0Kp = 0x40000000;             // Sturm count at p0 (CERT), packed: count + 4096, bit 30 = unsafe
     // ... and only on stacks where two modes cannot sit within one coarse interval: velocities that never
     // decrease with depth (no channel waves) and no layer thicker than three wavelengths of the period at
@@ -1184,7 +1234,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             const bool want_mag = want_ratio && st == ST_ELLIP;   // (the in-kernel ellipticity passes' cancellation test)
 #endif
             if (KIND == 2) val = EXACT ? delta_rayleigh_ref(wl, LS, S, mmj, cj, Tl, start)
-                                       : delta_rayleigh<(G != 2) && !FAST>(wl, LS, S, mmj, cj, Tl, start, phj, &vmag, want_mag);
+                                       : delta_rayleigh<(G != 2) && !FAST, CERT>(wl, LS, S, mmj, cj, Tl, start, phj, &vmag, want_mag, &kcj, &kuncj, coarse);
             // Love, NEVILL passes of the production kernel: DLTAR1 statement by statement on the production working stack (it holds
             // b, rho, d as the exact kernel's does).  A bracket goes to NEVILL because it may hold several roots, and which of them
             // NEVILL lands on depends on the VALUES it sees (its 10 x rule, its interpolation) - with e^{kd} of hundreds of km of

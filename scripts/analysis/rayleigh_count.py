@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Numerical check (CPU, float64) of a root COUNT for the Rayleigh secular function - the missing piece of a certified coarse
+scan for Rayleigh like the Love one.
+
+Candidate: the matrix Sturm / Morse-index count.  Y(z) = the two solutions that decay in the half space, integrated UP through the
+stack (motion-stress vectors (ur, uz, tz, tr), surfa.f:933-940); U(z), T(z) their displacement and traction 2 x 2 blocks.  The
+secular function is det T(0).  For a self-adjoint system the number of modes with phase velocity below the trial c (at fixed
+frequency) should be
+      N(c) = #{zeros of det U(z) between the half space and the surface} + #{negative eigenvalues of Z(0) = T U^-1 at the surface}
+(focal points + boundary index; sign conventions fixed empirically below).  This script measures, on random stacks:
+  1. whether that count equals the brute-force count of sign changes of det T(0) below c;
+  2. how FINE the stack must be stepped for "sign changes of det U at the step boundaries" to see every zero of det U - i.e. what a
+     recursion that carries the count would cost on top of the secular function's own layer steps.
+"""
+import sys
+import numpy as np
+from scipy.linalg import expm
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+
+
+def layer_matrix(k, om, a, b, rho):
+    mu = rho * b * b; lam = rho * (a * a - 2 * b * b); l2m = lam + 2 * mu
+    A = np.zeros((4, 4))
+    # y = (ur, uz, tz, tr), surfa.f:933-940
+    A[0, 1] = -k; A[0, 3] = 1.0 / mu
+    A[1, 2] = 1.0 / l2m; A[1, 0] = k * lam / l2m
+    A[2, 1] = -om * om * rho; A[2, 3] = k
+    A[3, 2] = -k * lam / l2m; A[3, 0] = -om * om * rho + 4 * k * k * mu * (lam + mu) / l2m
+    return A
+
+
+def halfspace_start(k, om, c, a, b, rho):
+    ra = k * np.sqrt(abs((c / a) ** 2 - 1)); rb = k * np.sqrt(abs((c / b) ** 2 - 1))
+    gam = 2.0 / (c / b) ** 2; gm1 = gam - 1
+    det = k * k - ra * rb; h = rho * om * om
+    brkt = -gm1 * k + gam * ra * rb / k
+    return np.array([[1.0, 0.0], [0.0, 1.0], [-h * brkt / det, -h * rb / det], [-h * ra / det, -h * brkt / det]])
+
+
+def sweep(stack, T, c, nsub):
+    """returns (det T(0), number of sign changes of det U at the nsub step boundaries of every layer, eigenvalues of Z(0))"""
+    a, b, rho, d = stack
+    om = 2 * np.pi / T; k = om / c
+    Y = halfspace_start(k, om, c, a[-1], b[-1], rho[-1])
+    s_prev = np.sign(np.linalg.det(Y[:2])); nz = 0
+    for i in range(len(d) - 2, -1, -1):
+        P = expm(-layer_matrix(k, om, a[i], b[i], rho[i]) * d[i] / nsub)
+        for _ in range(nsub):
+            Y = P @ Y
+            s = np.sign(np.linalg.det(Y[:2]))
+            if s != s_prev and s != 0: nz += 1; s_prev = s
+        q, r = np.linalg.qr(Y)                       # renormalise (det r > 0 keeps the sign of det U)
+        if np.linalg.det(r) < 0: q[:, 0] = -q[:, 0]
+        Y = q
+        s_prev = np.sign(np.linalg.det(Y[:2]))
+    U, Tt = Y[:2], Y[[3, 2]]          # tractions ordered (tr, tz): with (ur, uz) the system is Hamiltonian and Z = T U^-1 symmetric
+    Z = Tt @ np.linalg.inv(U)
+    return np.linalg.det(Tt), nz, np.linalg.eigvals(0.5 * (Z + Z.T)).real, np.abs(Z - Z.T).max() / np.abs(Z).max()
+
+
+def random_stack():
+    L = int(rng.integers(4, 11))
+    b = np.sort(rng.uniform(2.8, 4.6, L)); b[1:-1] += rng.normal(0, 0.12, L - 2)       # some low-velocity zones
+    a = 1.76 * b; rho = 0.541 + 0.3601 * a; d = rng.uniform(4, 30, L); d[-1] = 0
+    return a, b, rho, d
+
+
+def main():
+    n_ok = n_tot = 0; need = []
+    rule_hits = {}
+    for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+        st = random_stack(); T = float(rng.uniform(4, 40))
+        cmin, cmax = 0.75 * st[1][:-1].min(), st[1][-1] * 0.999
+        cs = np.arange(cmin, cmax, 0.002)
+        vals = []
+        for c in cs:
+            dT, nz, ev, asym = sweep(st, T, c, 64)
+            vals.append((dT, nz, (ev < 0).sum(), (ev > 0).sum()))
+        dT = np.array([v[0] for v in vals]); nz = np.array([v[1] for v in vals]); nneg = np.array([v[2] for v in vals])
+        brute = np.concatenate([[0], np.cumsum(np.sign(dT[1:]) != np.sign(dT[:-1]))])
+        for name, cnt in (("focal", nz), ("focal + neg(Z)", nz + nneg), ("focal + pos(Z)", nz + np.array([v[3] for v in vals]))):
+            if name == "focal + pos(Z)" and not ((cnt - brute) == (cnt - brute)[0]).all():
+                bad = np.nonzero((cnt - brute) != (cnt - brute)[0])[0]
+                print("   rule breaks at c =", cs[bad][:6], "offsets", (cnt - brute)[bad][:6], "of", len(cs), "trial velocities")
+            off = cnt - brute
+            rule_hits[name] = rule_hits.get(name, 0) + int((off == off[0]).all())
+        n_tot += 1
+        # how coarse can the stepping be before sign changes at the step boundaries miss zeros of det U?
+        ctest = cs[:: max(1, len(cs) // 25)]
+        for ns in (1, 2, 4, 8):
+            miss = sum(sweep(st, T, c, ns)[1] != sweep(st, T, c, 64)[1] for c in ctest)
+            if miss == 0: need.append(ns); break
+        else: need.append(16)
+        print(f"case {case}: L={len(st[3])} T={T:.1f}  modes below the half-space velocity {brute[-1]}  steps per layer needed {need[-1]}", flush=True)
+    print("count rule holds (constant offset from the brute-force count over the whole c range) in", rule_hits, "of", n_tot, "cases")
+    print("steps per layer needed for the boundary sign changes to see every zero of det U: histogram", np.bincount(need))
+
+
+if __name__ == "__main__":
+    main()
+
+
+def table(seed_case=5):
+    """developer view: brute-force count, zeros of det U, zeros of det T over depth, eigenvalue signs of Z(0) along c for one case"""
+    global rng
+    rng = np.random.default_rng(0)
+    for _ in range(seed_case + 1):
+        st = random_stack(); T = float(rng.uniform(4, 40))
+    cmin, cmax = 0.75 * st[1][:-1].min(), st[1][-1] * 0.999
+    cs = np.arange(cmin, cmax, 0.01)
+    prev = None; brute = 0
+    for c in cs:
+        dT, nz, ev, asym = sweep(st, T, c, 64)
+        if prev is not None and np.sign(dT) != np.sign(prev): brute += 1
+        prev = dT
+        print(f"c={c:.3f} brute={brute} zerosU={nz} negZ={(ev < 0).sum()} posZ={(ev > 0).sum()} asym={asym:.1e} detT={dT:.2e}")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""GPU box: the certified Love scan (default) against the point-by-point scan (SURFDISP_EXACTSCAN) on random stacks - the two
-must agree BIT FOR BIT (same brackets, same refinement); any differing stack is a failed certificate.  SOAK_SECONDS, SOAK_SEED."""
+"""GPU box: the certified coarse scan (default; Love since r03, Rayleigh since r04: SOAK_KIND=2) against the point-by-point scan
+(SURFDISP_EXACTSCAN) on random stacks - the two must agree BIT FOR BIT (same brackets, same refinement); any differing stack is a
+failed certificate.  SOAK_SECONDS, SOAK_SEED, SOAK_KIND (1 Love, 2 Rayleigh), SOAK_CU=1: c+U calls instead of phase-only ones."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +9,10 @@ import torch
 from pysurfinv_amd import _lib, forward, synth
 rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "0")))
 T_END = time.time() + float(os.environ.get("SOAK_SECONDS", "120"))
+KIND = int(os.environ.get('SOAK_KIND', '1'))
+FLAGS = 0 if os.environ.get('SOAK_CU') == '1' else _lib.PHASE_ONLY
 nstack = ncase = nbad = 0
+dump = []
 t_last = time.time()
 while time.time() < T_END:
     L = int(rng.integers(2, 48)); B = int(rng.integers(64, 2048)) * 16
@@ -32,21 +36,26 @@ while time.time() < T_END:
     dn = None if nlay is None else torch.from_numpy(nlay).cuda()
     plan = forward.BatchPlan(B, L, P)
     indep = bool(rng.random() < 0.15)
-    c1, u1, s1 = (t.clone() for t in plan.run(dm, dp, kind=1 | _lib.PHASE_ONLY, nlay=dn, independent=indep))
-    c0, u0, s0 = plan.run(dm, dp, kind=1 | _lib.PHASE_ONLY | _lib.EXACTSCAN, nlay=dn, independent=indep)
+    c1, u1, s1 = (t.clone() for t in plan.run(dm, dp, kind=KIND | FLAGS, nlay=dn, independent=indep))
+    c0, u0, s0 = plan.run(dm, dp, kind=KIND | FLAGS | _lib.EXACTSCAN, nlay=dn, independent=indep)
     torch.cuda.synchronize()
     diff = ((c1 != c0).any(dim=1) | (s1 != s0))
     nb = int(diff.sum())
     nstack += B; ncase += 1; nbad += nb
     if nb:
         i = int(diff.nonzero()[0, 0])
-        if os.environ.get("SOAK_DUMP") and not os.path.exists(os.environ["SOAK_DUMP"]):
-            idx = diff.nonzero()[:, 0].cpu().numpy()[:8]
-            np.savez(os.environ["SOAK_DUMP"], model=model[idx], per=per, nlay=(nlay[idx] if nlay is not None else np.full(len(idx), L)),
-                     c1=c1[idx].cpu().numpy(), c0=c0[idx].cpu().numpy(), team=team)
+        if os.environ.get("SOAK_DUMP") and len(dump) < 400:
+            for q in diff.nonzero()[:, 0].cpu().numpy()[:16]:
+                m48 = np.zeros((5, 48), np.float32); m48[:, :L] = model[q]
+                p40 = np.zeros(40, np.float32); p40[:P] = per
+                pad = lambda a: np.pad(a, (0, 40 - P))
+                dump.append(dict(model=m48, nlay=int(nlay[q]) if nlay is not None else L, per=p40, P=P, team=team, indep=int(indep),
+                                 c1=pad(c1[q].cpu().numpy()), c0=pad(c0[q].cpu().numpy())))
         print(f"  DIFFERS: L={L} B={B} P={P} team={team} indep={indep} noise={noise} mono={mono}: {nb} stacks; first {i}: c {c1[i].cpu().numpy()} vs {c0[i].cpu().numpy()}", flush=True)
     if time.time() - t_last > 45:
         print(f"  ... {ncase} cases, {nstack} stacks, {nbad} differing", flush=True); t_last = time.time()
 _lib.lib().surfdisp_set_team(0)
-print(f"certified Love scan vs point-by-point scan: {ncase} cases, {nstack} stacks, {nbad} differing stacks")
+if dump:
+    np.savez_compressed(os.environ['SOAK_DUMP'], **{k: np.array([d[k] for d in dump]) for k in dump[0]})
+print(f"certified {'Love' if KIND == 1 else 'Rayleigh'} scan vs point-by-point scan: {ncase} cases, {nstack} stacks, {nbad} differing stacks")
 sys.exit(1 if nbad else 0)

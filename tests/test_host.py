@@ -21,7 +21,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.surfdisp_abi_version() == 3
+    assert L.surfdisp_abi_version() == 4
     assert L.surfdisp_kernel_name(1) == b"surfdisp_phase_kernel"
 
 
