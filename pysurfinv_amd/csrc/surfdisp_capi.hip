@@ -31,6 +31,7 @@ struct EnvKnobs {
     float ell_ambig = 3.0e-3f;    // SURFDISP_ELL_AMBIG (developer knob): ellipticity closures below this fraction of their terms' magnitude are
                                   // evaluated again with the reference's arithmetic (0 = off)
     float ell_gmax = 25.0f;       // SURFDISP_ELL_GMAX (developer knob): ... and where 2 b^2 / c^2 of the stack's fastest layer exceeds this
+    int group_order = -1;         // SURFDISP_GROUP_ORDER (developer knob): workgroup order of the group-velocity kernel (-1: the library's rule; 0: plain period-major; g: XCD-aware, g stack blocks at a time)
     float phimulti = 1.0f;        // SURFDISP_PHIMULTI (developer knob): vertical-phase growth (rad) across a bracket beyond which NEVILL refines it
     bool fastscan = false;        // SURFDISP_FASTSCAN=1: opt every call of the process into the heuristic scan
     int device = 0;               // SURFDISP_DEVICE (fast_surf_)
@@ -58,6 +59,7 @@ struct EnvKnobs {
         if (const char *e = getenv("SURFDISP_SCAN_PHASE")) phimax = (float)atof(e);
         if (const char *e = getenv("SURFDISP_AMBIG")) ambig = (float)atof(e);
         if (const char *e = getenv("SURFDISP_PHIMULTI")) phimulti = (float)atof(e);
+        if (const char *e = getenv("SURFDISP_GROUP_ORDER")) group_order = atoi(e);
         if (const char *e = getenv("SURFDISP_ELL_AMBIG")) ell_ambig = (float)atof(e);
         if (const char *e = getenv("SURFDISP_ELL_GMAX")) ell_gmax = (float)atof(e);
         if (const char *e = getenv("SURFDISP_FASTSCAN")) fastscan = atoi(e) != 0;
@@ -397,7 +399,7 @@ static int forward_device_impl(void *stream, int B, int Lmax, const int *nlay,
         khs = reinterpret_cast<int *>(q);
     }
     sd::GroupArgs ga{B, Lmax, P, w.mdl, w.nl, per, w.ct, w.ratio, w.nsolved, w.ut, gdbg, kb, ka, kr, kscr, kscale, khs,
-                     kern_raw ? 1 : 0};
+                     kern_raw ? 1 : 0, 0, 0, kn.group_order};
     if (!phase_only) SD_HIP(sd::launch_group(s, kind, ga));
     if (!phase_only && kscr) {
         // one launch for the three arrays: factor 1 / (dL/dk), zeros below each unit's half space, whole rows

@@ -80,6 +80,9 @@ struct GroupArgs {
     float *kscale;        // with kscr: [P][B] the unit's factor 1 / (dL/dk), 0 = no partials (unsolved / invalid unit)
     int *khs;             // with kscr: [P][B] deepest layer the unit wrote (-1: none)
     int kraw;             // SURFDISP_KERN_REFCOORD: partials in the reference's coordinates (unit chain factors)
+    int xcd_order;        // set by launch_group: workgroup -> (stack block, period) order that keeps a stack block's periods on one XCD
+    int krev;             // (developer knob, SURFDISP_GROUP_ORDER + 100: periods in descending order)
+    int group_order;      // SURFDISP_GROUP_ORDER: < 0 the library's rule (launch_group), 0 plain period-major order, g > 0: an XCD takes g stack blocks at a time
 };
 struct KernTransposeArgs {
     int B, P, Lmax, kind;

@@ -1045,44 +1045,40 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     };
 
     // growth of the vertical phase between two trial velocities over the first mm - 1 layers of the working stack (see the
-    // bracket branch of the scan); every lane of the team calls it.  The same walk notes which P and S velocities of the first
-    // mm layers lie INSIDE the bracket (kink_possible) - see REFINE's acceptance test.
-    bool kink_possible = false;
+    // bracket branch of the scan); every lane of the team calls it.  Returns 0 where two bounds already show it below
+    // A.phimulti: no layer's share exceeds omega d sqrt(1/c1^2 - 1/c2^2) per wave type (sqrt(x + e) - sqrt(x) <= sqrt(e)) and only
+    // layers that are oscillatory at c2 have one - first with the thickness of the whole working stack (dtot, summed once per
+    // period for the layer-dropping shortcut), then with the thickness of the oscillatory layers (a compare and an add per
+    // layer); the sum of square roots itself is left to the few brackets that pass both (Love, ten layers: it cost 5 % of the
+    // root search when every bracket formed it).
+    float dtot = 0.0f;
     auto bracket_phase = [&](float c1, float c2, int mm) -> float {
         const float om = 6.2831853f * __builtin_amdgcn_rcpf(T);
         const float i1 = __builtin_amdgcn_rcpf(c1 * c1), i2 = __builtin_amdgcn_rcpf(c2 * c2);
-        const float klo = i2 * 0.999998f, khi = i1 * 1.000002f;
+        const float sq = 1.001f * om * sqrt_hw(fmaxf(i1 - i2, 0.0f));
+        if (sq * dtot * ((KIND == 2) ? 2.0f : 1.0f) <= A.phimulti) return 0.0f;
+        float dosc = 0.0f;
+        for (int i = j; i < mm - 1; i += G) {
+            const float d = W_D(i);
+            if (KIND == 2) dosc += ((W_IB2(i) > i2) ? d : 0.0f) + ((W_IA2(i) > i2) ? d : 0.0f);
+            else           dosc += (W_B(i) < c2) ? d : 0.0f;
+        }
+#pragma unroll
+        for (int d = G >> 1; d > 0; d >>= 1) dosc += __shfl_xor(dosc, d);
+        if (sq * dosc <= A.phimulti) return 0.0f;
         float sum = 0.0f;
-        bool hit = false;
-        for (int i = j; i < mm; i += G) {
-            const float od = (i < mm - 1) ? om * W_D(i) : 0.0f;                  // (the half space: no thickness, but a velocity)
+        for (int i = j; i < mm - 1; i += G) {
+            const float od = om * W_D(i);
             const float ib2 = (KIND == 2) ? W_IB2(i) : W_IR(i) * W_R(i);       // 1/b^2 (0: liquid)
             sum += od * (sqrt_hw(fmaxf(ib2 - i2, 0.0f)) - sqrt_hw(fmaxf(ib2 - i1, 0.0f)));
-            hit = hit || (ib2 >= klo && ib2 <= khi);
             if (KIND == 2) {
                 const float ia2 = W_IA2(i);
                 sum += od * (sqrt_hw(fmaxf(ia2 - i2, 0.0f)) - sqrt_hw(fmaxf(ia2 - i1, 0.0f)));
-                hit = hit || (ia2 >= klo && ia2 <= khi);
             }
         }
 #pragma unroll
         for (int d = G >> 1; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
-        kink_possible = (__ballot(hit) & tmask) != 0ull;
         return fabsf(sum);
-    };
-
-    // is 1/v^2 of a P or S velocity of the first mm layers of the working stack within [ilo, ihi]?  (every lane of the team)
-    auto kink_inside = [&](float ilo, float ihi, int mm) -> bool {
-        int hit = 0;
-#pragma unroll 1
-        for (int i = j; i < mm; i += G) {
-            const float ib2 = (KIND == 2) ? W_IB2(i) : W_IR(i) * W_R(i);
-            hit |= (ib2 >= ilo && ib2 <= ihi) ? 1 : 0;
-            if (KIND == 2) { const float ia2 = W_IA2(i); hit |= (ia2 >= ilo && ia2 <= ihi) ? 1 : 0; }
-        }
-#pragma unroll
-        for (int d = G >> 1; d > 0; d >>= 1) hit |= __shfl_xor(hit, d);
-        return hit != 0;
     };
 
     // Rayleigh, production kernel: can a matrix ENTRY of the reference overflow fp32 in this period although the
@@ -1108,6 +1104,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         for (int i = j; i < n; i += G) dsum += W_D(i);
 #pragma unroll
         for (int d = G >> 1; d > 0; d >>= 1) dsum += __shfl_xor(dsum, d);
+        dtot = dsum;                                                       // (bracket_phase's first bound)
         return dsum * 1.00001f <= FACT * c_lo * T;
     };
 
@@ -1134,6 +1131,15 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
 
     int wprio = -1;
     const bool LOCK = !EXACT && (INDEP ? A.lockstep >= 2 : A.lockstep != 0);
+    // NEVILL's prologue, surfa.f:12-16, from the scan's bracket (del1 is the scan's value, whatever layer dropping it was computed
+    // with - as in the reference)
+    auto nevill_start = [&]() {
+        nv_ic = 0; nv_nev = 1; nv_m = 1;
+        croot = (p0c + cb) / 2.0f;                             // c3, evaluated by the next pass
+        st = (KIND == 1 && !EXACT) ? ST_NEVILL0 : ST_NEVILL;   // (Love: first the end values in the reference's arithmetic)
+        sub = 0;
+        if (!EXACT && j == 0 && A.amb_count) atomicAdd(A.amb_count, 1);     // (statistics)
+    };
     while (__any(st != ST_DONE)) {
 #ifdef SD_WAVECLOCK
         const unsigned long long wp0 = __builtin_readcyclecounter();
@@ -1241,7 +1247,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             // layer the production recursion's values differ from the reference's by whole orders of magnitude, or are inf where
             // those are finite (r04 soak, thick-layer family, Love: 2e-4 of the stacks on another overtone with the production
             // values, 1.4e-2 before there was a NEVILL for such brackets at all).
+#ifndef SD_NO_LOVE_REFNEV
             else if (!EXACT && (st == ST_NEVILL || st == ST_NEVILL0)) val = delta_love_ref_body(wl, LS, S, mmj, cj, Tl);
+#endif
             else           val = EXACT ? delta_love_ref(wl, LS, S, mmj, cj, Tl) : delta_love<CERT>(wl, LS, S, mmj, cj, Tl, phj, kcj, kuncj, coarse,
 #ifdef SD_AMBIG
                                                                                                       &vmag
@@ -1463,17 +1471,13 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 // the G points of the first refine pass) only sees roots further apart than its points.  r04 soak: 4e-3 of
                 // the soft-sediment family's Love stacks came back on another overtone (1 .. 15 % off) from teams of <= 8
                 // lanes.  The phase is summed by the team, once per bracket (a layer per lane and turn).
-                #ifdef SD_NO_PHASEMULTI
-                if (EXACT) {
+                // (Lock step: the teams of a wavefront find their brackets in different passes, and a block run for one team
+                // costs the wavefront as much as for all - the phase is summed when all of them leave ST_WREF together, below.)
+#ifdef SD_NO_PHASEMULTI
+                if (EXACT) nevill_start();
 #else
-                if (EXACT || bracket_phase(p0c, cb, mm_frozen) > A.phimulti) {
-#endif   // NEVILL's prologue, surfa.f:12-16 (del1 is the scan's value, whatever layer dropping it was computed with - as in the reference)
-                    nv_ic = 0; nv_nev = 1; nv_m = 1;
-                    croot = (p0c + cb) / 2.0f;                 // c3, evaluated by the next pass
-                    st = (KIND == 1 && !EXACT) ? ST_NEVILL0 : ST_NEVILL;   // (Love: first the end values in the reference's arithmetic)
-                    sub = 0;
-                    if (!EXACT && j == 0 && A.amb_count) atomicAdd(A.amb_count, 1);     // (statistics)
-                }
+                if (EXACT || (!LOCK && bracket_phase(p0c, cb, mm_frozen) > A.phimulti)) nevill_start();
+#endif
             } else if (fl >= 0) {
                 failed = true;                                 // label 250
             } else {
@@ -1592,8 +1596,12 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 // lanes).  The values are brought to order one by a common power of two first (exact).
                 const float fm = fmaxf(fabsf(p0d), fabsf(db));
                 const int fex = (fm > 0.0f && fin(fm)) ? __builtin_amdgcn_frexp_expf(fm) : 0;
+#ifdef SD_NO_FSCALE
+                const float f0 = p0d, f1 = db, f2 = td;
+#else
                 const float f0 = ldexpf(p0d, -fex), f1 = ldexpf(db, -fex), f2 = ldexpf(td, -fex);
                 ud = ldexpf(ud, -fex);
+#endif
                 auto qt = [](float a, float bq) { return a * __builtin_amdgcn_rcpf(bq); };
                 float ts = qt(-f0 * w, f1 - f0);
                 float t = qt(w * (f0 * f2), (f1 - f0) * (f1 - f2)) + qt(sx * (f0 * f1), (f2 - f0) * (f2 - f1));
@@ -1624,22 +1632,21 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                     agree = (t2 >= 0.0f) && (t2 <= w) && (fabsf(t - t2) <= A.atol);
                 }
                 ++passes;                                          // hard bound: fp32 cannot resolve <1 ulp
-                // ... and never across a KINK: where c passes a layer's P or S velocity the layer turns from evanescent to
-                // oscillatory and the secular function behaves like sign(x) sqrt|x| there (the half-space closure is linear in
-                // sqrt|c^2/b^2 - 1|).  With such a velocity among the points an estimate is built from, all three-point
-                // estimates miss alike and still agree (ragged fixture, 60 s: root 5e-6 km/s below a layer's S velocity; teams
-                // of 16 lanes accepted a 3.5e-5 bracket and came out 8e-6 off, 1e-3 of U; NEVILL - and teams of any other size -
-                // within 6e-7).
+                // ... and never across the KINK at the cut-off: a layer of finite thickness enters the secular function through
+                // even functions of its vertical wavenumbers (cos, sin(x)/x, x sin(x)) and is smooth where c passes its P or S
+                // velocity, but the half-space closure is LINEAR in sqrt|1 - c^2/b^2|: at the S velocity of the working stack's
+                // half space the function behaves like sqrt|x|.  With that velocity among the points an estimate is built
+                // from, all three-point estimates miss alike and still agree (ragged fixture, 60 s: root 5e-6 km/s below the
+                // half space's S velocity; teams of 16 lanes accepted a 3.5e-5 bracket and came out 8e-6 off, 1e-3 of U at
+                // |dlnU/dlnc| = 485; NEVILL - and teams of any other size - within 6e-7).  A bracket that reaches up to the
+                // cut-off is subdivided until it no longer does (roots lie below it, calcul.f:191).
                 bool accept = !(w > 1.0e-6f) || passes > 64;
                 if (!accept && !(w > A.wtol) && agree) {
 #ifndef SD_NO_KINK
-                    // (the bracket itself: with the kink between the bracket and ONE of the outer points the two estimates - one
-                    // built across it, one not - disagree by themselves.  Whether ANY velocity lies inside the SCAN's bracket was
-                    // noted when it was found (bracket_phase; usually none); only then the working stack is walked again.)
-                    if (kink_possible) {
-                        const float jlo = __builtin_amdgcn_rcpf(p0c * p0c) * 1.000002f, jhi = __builtin_amdgcn_rcpf(cb * cb) * 0.999998f;
-                        accept = !kink_inside(jhi, jlo, mm_frozen);
-                    } else accept = true;
+                    accept = !(W_B(mm_frozen - 1) <= cb * 1.000001f);
+#ifdef SD_COUNT_KINK
+                    if (j == 0 && A.amb_count && !accept) atomicAdd(A.amb_count + 1, 1);   // (developer statistics: refine passes added by the kink test)
+#endif
 #else
                     accept = true;
 #endif
@@ -1694,7 +1701,12 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             // root waits until all have theirs: one refine pass and one end-of-period block per period and wavefront.  A
             // waiting team evaluates nothing; each team's own sequence of evaluations - and so every result - is unchanged.
             if (solved) { st = ST_WEND; solved = false; }
-            if (!__any(st == ST_SCAN) && st == ST_WREF) st = ST_REFINE;
+            if (!__any(st == ST_SCAN) && st == ST_WREF) {
+                st = ST_REFINE;
+#ifndef SD_NO_PHASEMULTI
+                if (bracket_phase(p0c, cb, mm_frozen) > A.phimulti) nevill_start();      // (see the bracket branch of the scan)
+#endif
+            }
             if (!__any(st == ST_SCAN || st == ST_WREF || st == ST_REFINE || st == ST_NEVILL || st == ST_NEVILL0 || st == ST_ELLIP) && st == ST_WEND)
                 solved = true;
         }
@@ -2544,10 +2556,27 @@ template <int KIND, bool KERN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KERN ? SD_KERN_WAVES : SD_GROUP_WAVES, 8)))
 void surfdisp_group_kernel(GroupArgs A)
 {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int B = A.B, P = A.P;
-    if (idx >= (size_t)B * P) return;
-    const int b = (int)(idx % B), k = (int)(idx / B);       // a wavefront = 64 stacks, one period
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int b, k;                                               // a wavefront = 64 stacks, one period
+    if (A.xcd_order) {
+        // Workgroups go to the 8 XCDs in turn (blockIdx % 8), each with its own L2.  In plain period-major order the P
+        // workgroups that read the same 256 stacks are B/256 launches apart and every one of them fetches the stacks from HBM
+        // again, once per sweep (16 384 x L64 x P20: 0.5 .. 0.8 GB per launch for 17 MB of stacks).  Here XCD x takes the stack
+        // blocks x, x + 8, ... g at a time, period by period: the P readers of a stack block run on one XCD, close in time.
+        const int g = A.xcd_order;                          // stack blocks an XCD works on at a time, period by period
+        const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int r = q % (g * P);
+        k = r / g;
+        b = (((q / (g * P)) * g + r % g) * 8 + x) * 256 + (int)threadIdx.x;
+        if (b >= B) return;
+        if (A.krev) k = P - 1 - k;
+        idx = (size_t)k * B + b;
+    } else {
+        if (idx >= (size_t)B * P) return;
+        b = (int)(idx % B); k = (int)(idx / B);
+        if (A.krev) { k = P - 1 - k; idx = (size_t)k * B + b; }
+    }
     const size_t o = idx;                                   // period-major [P][B]: coalesced
     const int n = A.nl[b];
     KOut ko{nullptr, 1, 0, 0, 0};
@@ -2806,11 +2835,25 @@ hipError_t launch_finish(hipStream_t s, const FinishArgs &a)
     return hipGetLastError();
 }
 
-hipError_t launch_group(hipStream_t s, int kind, const GroupArgs &a)
+hipError_t launch_group(hipStream_t s, int kind, const GroupArgs &a_in)
 {
+    GroupArgs a = a_in;
     const size_t total = (size_t)a.B * a.P;
-    const int grid = (int)((total + 255) / 256);
+    int grid = (int)((total + 255) / 256);
     const bool kern = a.kb != nullptr;
+    // Workgroup order (see the kernel).  group_order < 0 (default): the XCD-aware order, four stack blocks per XCD at a time, for the
+    // launches that also write the partials when every XCD gets the same number (<= 8) of stack blocks; plain period-major order
+    // otherwise.  Measured (16 384 x L64 / 25 600 x L96, P20, Rayleigh; profiles/r04b/group_order.txt): with the partials
+    // 535 us + 808 MB fetched in plain order, 533 us + 216 MB with four blocks at a time, 565 us + 75 MB with one; without them
+    // 471 / 502 / 499 us (the plain launch is not worth it); 25 600 stacks (12.5 blocks per XCD: uneven shares) 1.25 ms plain,
+    // 1.39 .. 1.55 ms in every grouped order.
+    const int nblk = (a.B + 255) / 256;
+    int g = a.group_order;
+    if (g < 0) g = (kern && a.B % 2048 == 0 && nblk / 8 <= 8) ? (nblk / 8 < 4 ? nblk / 8 : 4) : 0;
+    a.krev = g >= 100 ? 1 : 0;
+    g %= 100;
+    a.xcd_order = (nblk >= 8 && a.B % 256 == 0 && g > 0) ? g : 0;
+    if (a.xcd_order) grid = (((nblk + 7) / 8 + a.xcd_order - 1) / a.xcd_order) * a.xcd_order * 8 * a.P;
     if (kind == 2 && kern)  hipLaunchKernelGGL((surfdisp_group_kernel<2, true>), dim3(grid), dim3(256), 0, s, a);
     else if (kind == 2)     hipLaunchKernelGGL((surfdisp_group_kernel<2, false>), dim3(grid), dim3(256), 0, s, a);
     else if (kern)          hipLaunchKernelGGL((surfdisp_group_kernel<1, true>), dim3(grid), dim3(256), 0, s, a);
