@@ -1233,6 +1233,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         }
 #endif
         float vmag = 0.0f;                                     // magnitude of the terms the value is the sum of (production recursion)
+#if defined(SD_AMBIG) && SD_AMBIG == 2
+        bool amb_defer = false;
+#endif
         if (eval) {
 #ifdef SD_AMBIG
             const bool want_mag = true;
@@ -1266,9 +1269,17 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         // A.amb_count); the wavefront's other lanes wait for it.
 #ifdef SD_AMBIG
         if (!EXACT && eval && st == ST_SCAN && !ell_lane && A.ambig > 0.0f && fabsf(val) < A.ambig * vmag) {
+#if SD_AMBIG == 2   // (second experiment: the whole stack to the exact fallback kernel - the reference's arithmetic on the reference's own inputs)
+            amb_defer = true;
+#else
             val = (KIND == 2) ? delta_rayleigh_ref_body<true>(wl, LS, S, mmj, cj, Tl, 1) : delta_love_ref_body(wl, LS, S, mmj, cj, Tl);
+#endif
             if (A.amb_count) atomicAdd(A.amb_count, 1);
         }
+#if SD_AMBIG == 2
+        if ((__ballot(amb_defer) & tmask) != 0ull) defer = true;
+        amb_defer = false;
+#endif
 #endif
         // ... and the in-kernel ellipticity passes (two-lane teams) likewise: a closure that is the remainder of a cancellation
         // marks the (stack, period) for the ellipticity kernel, which evaluates both passes with the reference's arithmetic
