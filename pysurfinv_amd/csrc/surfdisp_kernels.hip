@@ -1081,12 +1081,33 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         return fabsf(sum);
     };
 
-    // Rayleigh, production kernel: can a matrix ENTRY of the reference overflow fp32 in this period although the
-    // factorised recursion stays finite?  The largest entry is a51 ~ rhoc^2 g^4 rsinp rsinq <= rhoc^2 g^4 e^(pm+qm)
+    // Production kernel: can the reference's arithmetic overflow fp32 in this period although the production recursion stays
+    // finite?  Rayleigh (DLTAR4 normalises per layer): a matrix ENTRY.  The largest entry is a51 ~ rhoc^2 g^4 rsinp rsinq <= rhoc^2 g^4 e^(pm+qm)
     // with pm + qm <= 2 k d.  Bound it per stack (thickest layer, largest rho and Vs: prep kernel) at the lowest
     // trial velocity of the period; beyond e^84 the stack goes to the exact fallback.
+    // Love: DLTAR1 carries (ut, tt) through the layers WITHOUT normalisation (surfa.f:143-179): across the evanescent layers the
+    // pair grows like exp(sum of k d sqrt(1 - c^2/b^2)) and overflows fp32 beyond e^88 (or a single layer's exp(q) underflows and
+    // its reciprocal is inf) - the reference then scans NaNs, and returns the edge of the overflowed region as the root, while
+    // the production recursion (normalised) stays finite and finds the true one (r04 soaks: the Love stacks left on another
+    // root in the thick-layer and soft-sediment families, 100-km layers at 3-6 s, sediments at 0.3-1 s).  Summed at the period's
+    // lowest trial velocity - first against the thickness of the whole working stack (dtot: no sum needed for any of the
+    // bench workloads), then over the evanescent layers; from e^76 on (the rest of the margin: rho b^2 rb factors) the stack
+    // goes to the exact fallback.  Call after no_drop_possible (dtot).
     auto entry_overflow_risk = [&](float c_lo) -> bool {
-        if (EXACT || KIND != 2 || !team_valid) return false;
+        if (EXACT || !team_valid) return false;
+        if (KIND == 1) {
+            const float wv = 6.2831853f * __builtin_amdgcn_rcpf(c_lo * T);
+            if (wv * dtot < 76.0f) return false;
+            float sq = 0.0f;
+            const float c2 = c_lo * c_lo;
+            for (int i = j; i < n; i += G) {
+                const float bb = W_B(i);
+                sq += (bb > c_lo) ? W_D(i) * sqrt_hw(fmaxf(1.0f - c2 * __builtin_amdgcn_rcpf(bb * bb), 0.0f)) : 0.0f;
+            }
+#pragma unroll
+            for (int d = G >> 1; d > 0; d >>= 1) sq += __shfl_xor(sq, d);
+            return !(wv * sq < 76.0f);                                       // also when c_lo or T is not positive
+        }
         const float hthick = A.ovf[b], lnrho2 = A.ovf[(size_t)B + b], lng4 = A.ovf[2 * (size_t)B + b];
         const float c_hi = W_B(mm_carry - 1) + 0.31f;                      // upper guard of the scan, calcul.f:166
         const float lnmag = 12.566371f * hthick / (c_lo * T) + lnrho2 + 4.0f * __logf(c_hi) +
@@ -1123,8 +1144,8 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         p0c = qq * (1.0f + b_corr);
         if (water) p0c = 0.5f;
         first = true;
-        defer = (!EXACT && A.strict != 0) || entry_overflow_risk(p0c);    // SURFDISP_STRICT: everything to the exact kernel
         nodrop = no_drop_possible(p0c);
+        defer = (!EXACT && A.strict != 0) || entry_overflow_risk(p0c);    // SURFDISP_STRICT: everything to the exact kernel
         // CERT: a period in which no trial can drop layers (one eigenproblem for every trial velocity) starts on the coarse grid
         if (CERT) coarse = nodrop;
     }
@@ -1308,6 +1329,10 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         const bool has_prev = !((st == ST_SCAN) && first && (js == 0));
         auto negnan = [](float x) { return signbit(x) && !(x != x); };   // a NaN compares as positive, see below
         const bool cross = has_prev && (negnan(val) != negnan(pd));
+#ifdef SD_DEBUG_TRIALS   // (developer build: every evaluated trial of a one-stack call)
+        if (A.B == 1 && eval && k == SD_DEBUG_TRIALS && cj > SD_DEBUG_CMIN)
+            printf("k %d pass %d st %d lane %d c %.7f val % .6e mm %d | p0c %.7f p0d % .4e cb %.7f db % .4e\n", k, passes, st, j, cj, val, mmj, p0c, p0d, cb, db);
+#endif
         bool guard = false;
         if (st == ST_SCAN && has_prev && !cross)               // calcul.f:165-166
             guard = (cj < 0.8f * b1top) || !(cj < W_B(mmj - 1) + 0.3f);
@@ -1736,6 +1761,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
             else {
                 T = A.per[k];
                 mm_carry = mm_frozen;                          // mmax left by the last idrop=0 trial
+#ifdef SD_DEBUG_TRIALS
+                if (A.B == 1 && j == 0) printf("period %d starts: previous root %.7f, layers rebuilt for T = %.4f: %d of %d\n", k, croot, T, mm_carry, n);
+#endif
                 build(mm_carry);
                 nflat_cur = mm_carry;
                 b1top = W_B(0);
@@ -1743,8 +1771,8 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
                 p0d = 0.0f; p0mm = 0; p0ok = false; first = true; passes = 0;
                 coarse = false; fine_left = 1; q0ok = false;
                 st = ST_SCAN;
-                defer = entry_overflow_risk(p0c);              // acted on at the end of the next pass
                 nodrop = no_drop_possible(p0c);
+                defer = entry_overflow_risk(p0c);              // acted on at the end of the next pass
                 if (CERT) coarse = nodrop;
             }
         }

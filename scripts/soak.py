@@ -22,6 +22,10 @@ bad_cases = []
 KEEP = int(os.environ.get("SOAK_KEEP", "6000")); LCAP, PCAP = 48, 40
 off = dict(model=[], nlay=[], per=[], P=[], kind=[], team=[], cat=[], c=[], co=[], u=[], uo=[])
 TAG = os.environ.get("SOAK_TAG", (os.environ.get("SOAK_FAMILY") or "general") + ("_strict" if STRICT else "_oracle"))
+if os.environ.get("SOAK_RECLASSIFY"):                      # only the classification, of the offenders an earlier soak saved
+    _f = np.load(os.environ["SOAK_RECLASSIFY"])
+    off = {k: list(_f[k]) for k in off}
+    T_END = 0.0
 while time.time() < T_END:
     L = int(rng.integers(2, 48)); B = int(rng.integers(64, 2048)) * (16 if STRICT else 1); kind = int(rng.integers(1, 3))
     if os.environ.get("SOAK_KIND"):                        # one wave type only (1 Love, 2 Rayleigh)
@@ -105,7 +109,7 @@ while time.time() < T_END:
         T_LAST = time.time()
         print(f"  ... {ncase} cases, {nstack} stacks, pattern mismatches {npat}, flagged {len(bad_cases)}", flush=True)
 _lib.lib().surfdisp_set_team(0)
-if off["cat"]:
+if off["cat"] and not os.environ.get("SOAK_RECLASSIFY"):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"soak_offenders_{TAG}.npz"),
                         **{k: np.asarray(v) for k, v in off.items()})
@@ -114,6 +118,29 @@ if off["cat"]:
 # U moves by > 1e-4 for a 2e-6 change of c), when the reference's FMA and non-FMA builds disagree there by > 2e-5 or one of them
 # returns NaN, or in the overflow regime (NaN on either side); a phase velocity off by > 1e-4 only when the reference's two builds
 # disagree by that much themselves
+def near_scan_point(m, n, kind, per, P, k, croot, tol=3e-6):
+    """Is croot within tol (relative) of one of the trial velocities of the oracle's scan of period k (its 0.01 km/s grid)?
+    Then the SIGN of the secular function at that one trial - the remainder of a cancellation to the last bit - decides which
+    bracket the scan stops at: the mechanism behind every zero-pattern mismatch the soaks have shown, and, where overtones are
+    0.01 km/s apart, behind a root on the neighbouring overtone."""
+    import ctypes
+    fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
+    cap = 8192
+    ct = np.zeros(cap, np.float32); dt = np.zeros(cap, np.float32); mt = np.zeros(cap, np.int32)
+    rows = [np.ascontiguousarray(m[r], dtype=np.float32) for r in range(5)]
+    pp = np.ascontiguousarray(per, dtype=np.float32)
+    nt = cport.lib().surfdisp_oracle_scan_trace(int(n), int(kind), *[r.ctypes.data_as(fp) for r in rows], pp.ctypes.data_as(fp), int(P), int(k), 4,
+                                                ct.ctypes.data_as(fp), dt.ctypes.data_as(fp), mt.ctypes.data_as(ip), cap)
+    if nt <= 0 or not croot > 0: return False
+    if (np.abs(ct[:nt] / np.float32(croot) - 1) < tol).any(): return True
+    # ... or a trial whose value is below 2e-3 of BOTH neighbours' (a root a few 1e-5 km/s from the trial; thick layers with
+    # c ~ b: c^2/b^2 - 1 carries a relative rounding of 1e-5 there and the phase k d rb of tens of radians turns it into 1e-3 of
+    # the function's scale): the same mechanism with a wider band
+    a = np.abs(dt[:nt])
+    with np.errstate(all="ignore"):
+        inner = (a[1:-1] < 2e-3 * a[:-2]) & (a[1:-1] < 2e-3 * a[2:])
+    return bool(inner.any())
+
 def classify():
     from oracle import refso
     DC = 2e-6
@@ -142,12 +169,23 @@ def classify():
             cv, uv, sv = cport.forward_batch(m[None], per, kind)
             var.append((cv[0], uv[0]))
         cport.lib().surfdisp_oracle_set_variant(0)
+        # ... and the statement-by-statement kernel (SURFDISP_STRICT: the reference's formulas in the reference's order, on the GPU,
+        # with the GPU's exp / sin / cos): where IT leaves the oracle too, the last bit of the libm decides the result
+        cs, us, ss = forward.forward_batch(m[None], per, kind, strict=True)
+        cs, us = cs[0], us[0]
         k = 0
         with np.errstate(all="ignore"):
             if cat == 0:
                 why = "zero pattern: UNEXPLAINED"
                 if two and not np.array_equal(two[0][0] > 0, two[1][0] > 0): why = "zero pattern: the reference's builds differ too"
                 elif any(np.array_equal(cv > 0, c > 0) for cv, uv in var): why = "zero pattern: as the oracle's with another rounding of exp / flattening"
+                elif not np.array_equal(cs > 0, co > 0): why = "zero pattern: the statement-by-statement kernel (GPU libm) leaves the oracle too"
+                else:
+                    kd = int(np.nonzero((c > 0) != (co > 0))[0][0])      # first period with a root on one side only
+                    kq = kd if max(c[kd], co[kd]) > 0 else kd
+                    roots = [r for r in (c[kd], co[kd], c[kd - 1] if kd else 0.0, co[kd - 1] if kd else 0.0) if r > 0]
+                    if any(near_scan_point(m, n, kind, per, P, kk, r) for r in roots for kk in ({kd, max(kd - 1, 0)})):
+                        why = "zero pattern: a scan trial whose sign is within rounding (root within 3e-6 of it, or |value| < 2e-3 of both neighbours)"
             elif cat == 1:
                 bad = np.abs(c / co - 1) > 1e-4
                 k = int(np.nanargmax(np.abs(c / co - 1)))
@@ -156,6 +194,14 @@ def classify():
                 if sp > 1e-4: why = "c: the reference's builds disagree"
                 elif any((np.abs(c[bad] / cv[bad] - 1) < 2e-5).all() for cv, uv in var if (cv[bad] > 0).all()):
                     why = "c: as the oracle's with another rounding of exp / flattening"
+                elif (np.abs(cs[bad] / co[bad] - 1) > 1e-4).any(): why = "c: the statement-by-statement kernel (GPU libm) leaves the oracle too"
+                else:
+                    kd = int(np.nonzero(np.nan_to_num(np.abs(c / co - 1)) > 2e-5)[0][0])      # first period that differs
+                    # (the period before counts too: a bracket one grid step further on there leaves the same root but another
+                    # mmax behind, and the next period then rebuilds another number of layers for its T - calcul.f's carry-over)
+                    if near_scan_point(m, n, kind, per, P, kd, co[kd]) or near_scan_point(m, n, kind, per, P, kd, c[kd]) or \
+                       (kd > 0 and near_scan_point(m, n, kind, per, P, kd - 1, co[kd - 1])):
+                        why = "c: a scan trial whose sign is within rounding (root within 3e-6 of it, or |value| < 2e-3 of both neighbours); next overtone 0.01 km/s on"
             else:
                 e = np.nan_to_num(np.abs(u / uo - 1), nan=9.0)
                 e = np.where(~np.isfinite(uo) & ~np.isfinite(u), 0.0, e)
@@ -170,6 +216,7 @@ def classify():
                     if not np.isfinite(cond) or cond > 1e-4: why = "U: ill conditioned (|dlnU/dlnc| x 2e-6 > 1e-4)"
                     elif not np.isfinite(sp) or sp > 2e-5: why = "U: the reference's builds disagree"
                     elif any(abs(u[k] / uv[k] - 1) < 5e-5 for cv, uv in var if uv[k] != 0): why = "U: as the oracle's with another rounding of exp / flattening"
+                    elif abs(us[k] / uo[k] - 1) > 1e-4: why = "U: the statement-by-statement kernel (GPU libm) leaves the oracle too"
                     else: why = "U: UNEXPLAINED"
         counts[why] = counts.get(why, 0) + 1
         if "UNEXPLAINED" in why and len(unexpl) < 12:
