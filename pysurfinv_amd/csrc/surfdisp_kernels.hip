@@ -1085,28 +1085,23 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     // finite?  Rayleigh (DLTAR4 normalises per layer): a matrix ENTRY.  The largest entry is a51 ~ rhoc^2 g^4 rsinp rsinq <= rhoc^2 g^4 e^(pm+qm)
     // with pm + qm <= 2 k d.  Bound it per stack (thickest layer, largest rho and Vs: prep kernel) at the lowest
     // trial velocity of the period; beyond e^84 the stack goes to the exact fallback.
-    // Love: DLTAR1 carries (ut, tt) through the layers WITHOUT normalisation (surfa.f:143-179): across the evanescent layers the
-    // pair grows like exp(sum of k d sqrt(1 - c^2/b^2)) and overflows fp32 beyond e^88 (or a single layer's exp(q) underflows and
-    // its reciprocal is inf) - the reference then scans NaNs, and returns the edge of the overflowed region as the root, while
-    // the production recursion (normalised) stays finite and finds the true one (r04 soaks: the Love stacks left on another
-    // root in the thick-layer and soft-sediment families, 100-km layers at 3-6 s, sediments at 0.3-1 s).  Summed at the period's
-    // lowest trial velocity - first against the thickness of the whole working stack (dtot: no sum needed for any of the
-    // bench workloads), then over the evanescent layers; from e^76 on (the rest of the margin: rho b^2 rb factors) the stack
-    // goes to the exact fallback.  Call after no_drop_possible (dtot).
+    // Love: DLTAR1 carries (ut, tt) through the layers WITHOUT normalisation (surfa.f:143-179): across evanescent layers the pair
+    // grows like exp(sum of k d sqrt(1 - c^2/b^2)) and overflows fp32 beyond e^88 (or a layer's exp(q) underflows and its
+    // reciprocal is inf) - the reference then scans NaNs and returns the edge of the overflowed region as the root, while the
+    // production recursion stays finite and finds the true one.  Layer dropping bounds that sum: the layer at which the
+    // evanescent thickness passes 4 c T becomes the half space, so the layers above it hold at most k x 4 c T = 8 pi of
+    // exponent - EXCEPT when the TOP layer alone passes it (mmax is at least 2, surfa.f:105: the top layer stays a layer
+    // whatever its thickness).  That one product, at the period's lowest trial velocity, decides: from e^76 on (the rest of the
+    // margin: the 8 pi of further layers are not possible then, rho b^2 rb factors are) the stack goes to the exact fallback.
+    // 200-km top layers at T < 3 s; no stack of the bench workloads.
     auto entry_overflow_risk = [&](float c_lo) -> bool {
         if (EXACT || !team_valid) return false;
         if (KIND == 1) {
-            const float wv = 6.2831853f * __builtin_amdgcn_rcpf(c_lo * T);
-            if (wv * dtot < 76.0f) return false;
-            float sq = 0.0f;
-            const float c2 = c_lo * c_lo;
-            for (int i = j; i < n; i += G) {
-                const float bb = W_B(i);
-                sq += (bb > c_lo) ? W_D(i) * sqrt_hw(fmaxf(1.0f - c2 * __builtin_amdgcn_rcpf(bb * bb), 0.0f)) : 0.0f;
-            }
-#pragma unroll
-            for (int d = G >> 1; d > 0; d >>= 1) sq += __shfl_xor(sq, d);
-            return !(wv * sq < 76.0f);                                       // also when c_lo or T is not positive
+            const float bb = W_B(0);                                        // (water on top, b = 0: never counted, never kept)
+            if (!(bb > c_lo)) return !(c_lo > 0.0f && T > 0.0f);
+            const float q0 = 6.2831853f * __builtin_amdgcn_rcpf(c_lo * T) * W_D(0) *
+                             sqrt_hw(fmaxf(1.0f - c_lo * c_lo * __builtin_amdgcn_rcpf(bb * bb), 0.0f));
+            return !(q0 < 76.0f);                                           // also when c_lo or T is not positive
         }
         const float hthick = A.ovf[b], lnrho2 = A.ovf[(size_t)B + b], lng4 = A.ovf[2 * (size_t)B + b];
         const float c_hi = W_B(mm_carry - 1) + 0.31f;                      // upper guard of the scan, calcul.f:166

@@ -484,6 +484,32 @@ def test_independent_mode_failure_cascade_and_water(hip, ref_cases):
     assert np.isfinite(c).all() and c.shape == d["c"].shape
 
 
+def test_love_overflow_stacks_go_through_the_exact_kernel(hip):
+    """DLTAR1 carries (ut, tt) through the layers without normalisation (surfa.f:143-179): three 300 km layers at 2-4 s put
+    e^(several hundred) into the pair, the reference scans NaNs and returns the edge of the overflowed region.  The production
+    Love recursion stays finite there, so the root search bounds the growth per period (sum of k d sqrt(1 - c^2/b^2) over the
+    evanescent layers at the lowest trial velocity) and hands such stacks to the exact fallback kernel: every one of them is
+    re-solved there, and the default call returns what SURFDISP_STRICT returns, bit for bit, for every team size."""
+    import torch
+    from pysurfinv_amd import forward, synth, _lib
+    B, L, P = 192, 4, 6
+    m = synth.synth_models(B, L, seed=11, noise=0.05, monotone=True, total_thickness=900.0)
+    per = np.linspace(2.0, 4.0, P).astype(np.float32)
+    mt, pt = torch.from_numpy(m).cuda(), torch.from_numpy(per).cuda()
+    plan = forward.BatchPlan(B, L, P)
+    cs, us, ss = [t.clone() for t in plan.run(mt, pt, kind=1 | _lib.STRICT)]
+    for team in (0, 1, 2, 8, 64):
+        assert _lib.lib().surfdisp_set_team(team) == 0
+        try:
+            c, u, st = plan.run(mt, pt, kind=1)
+            torch.cuda.synchronize()
+            assert plan.counters()[0] == B                          # every stack was handed over
+        finally:
+            _lib.lib().surfdisp_set_team(0)
+        assert torch.equal(st, ss) and torch.equal(c, cs)
+        assert torch.equal(torch.nan_to_num(u, nan=-1.0), torch.nan_to_num(us, nan=-1.0))
+
+
 def test_fp32_overflow_regime_follows_the_reference(hip):
     """Two 200 km layers at T = 5 s: the un-normalised secular function overflows fp32 (NaN / inf) below ~3.0 km/s.
     The reference's scan treats a NaN as positive, brackets the edge of the overflowed region, and NEVILL - whose

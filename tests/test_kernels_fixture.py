@@ -216,6 +216,31 @@ def test_partials_through_the_scratch_equal_the_direct_route(kind):
     assert float(big[3].abs().max()) > 0.0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [2, 1])
+def test_partials_do_not_depend_on_the_workgroup_order(kind):
+    """A launch of the group-velocity kernel that also writes the partials, over a whole number of 2 048-stack blocks, deals its
+    workgroups to the XCDs so that the periods of a stack block share one L2 (launch_group); any other batch size runs in plain
+    period-major order.  A unit's arithmetic does not depend on where it runs: 4 096 stacks in one call (XCD-aware order) equal
+    the same stacks in two calls of 2 000 and 2 096 (plain order), bit for bit."""
+    import torch
+    from pysurfinv_amd import forward, synth
+    B, L, P = 4096, 9, 7
+    m = torch.from_numpy(synth.synth_models(B, L, seed=21, noise=0.05)).cuda()
+    per = torch.from_numpy(synth.default_periods(P)).cuda()
+    whole = [t.clone() if t is not None else None for t in forward.BatchPlan(B, L, P).run_kernels(m, per, kind=kind)]
+    parts = []
+    for lo, hi in ((0, 2000), (2000, B)):
+        parts.append([t.clone() if t is not None else None
+                      for t in forward.BatchPlan(hi - lo, L, P).run_kernels(m[lo:hi].contiguous(), per, kind=kind)])
+    for q, a in enumerate(whole):
+        if a is None:
+            assert parts[0][q] is None
+            continue
+        assert torch.equal(a, torch.cat([parts[0][q], parts[1][q]]))
+    assert float(whole[3].abs().max()) > 0.0
+
+
 # ---- the analytic partials against the reference's OWN numbers (COMMON /rar1/, tests/golden/make_golden_partials.py)
 PART = np.load(os.path.join(HERE, "golden", "ref_partials.npz"))
 
