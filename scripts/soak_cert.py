@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: the certified coarse scan (default; Love since r03, Rayleigh since r04: SOAK_KIND=2) against the point-by-point scan
 (SURFDISP_EXACTSCAN) on random stacks - the two must agree BIT FOR BIT (same brackets, same refinement); any differing stack is a
-failed certificate.  SOAK_SECONDS, SOAK_SEED, SOAK_KIND (1 Love, 2 Rayleigh), SOAK_CU=1: c+U calls instead of phase-only ones."""
+failed certificate.  SOAK_SECONDS, SOAK_SEED, SOAK_KIND (1 Love, 2 Rayleigh), SOAK_CU=1: c+U calls instead of phase-only ones, SOAK_DEEP=1: stacks of up to 96 layers (default: below 48)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,7 @@ nstack = ncase = nbad = 0
 dump = []
 t_last = time.time()
 while time.time() < T_END:
-    L = int(rng.integers(2, 48)); B = int(rng.integers(64, 2048)) * 16
+    L = int(rng.integers(2, 97 if os.environ.get('SOAK_DEEP') == '1' else 48)); B = int(rng.integers(64, 2048)) * (16 if L < 48 else 4)
     noise = float(rng.choice([0.02, 0.05, 0.1, 0.2])); mono = bool(rng.random() < 0.5)
     fam = rng.random()
     if fam < 0.25 and L >= 4:
@@ -30,7 +30,7 @@ while time.time() < T_END:
     nlay = None
     if rng.random() < 0.3:
         nlay = rng.integers(2, L + 1, B).astype(np.int32)
-    team = int(rng.choice([0, 0, 2, 4, 8]))
+    team = int(rng.choice([0, 0, 1, 2, 4, 8]))
     _lib.lib().surfdisp_set_team(team)
     dm, dp = torch.from_numpy(model).cuda(), torch.from_numpy(per).cuda()
     dn = None if nlay is None else torch.from_numpy(nlay).cuda()
@@ -40,6 +40,8 @@ while time.time() < T_END:
     c0, u0, s0 = plan.run(dm, dp, kind=KIND | FLAGS | _lib.EXACTSCAN, nlay=dn, independent=indep)
     torch.cuda.synchronize()
     diff = ((c1 != c0).any(dim=1) | (s1 != s0))
+    if not (FLAGS & _lib.PHASE_ONLY):                        # c+U: the group velocities too (NaN = NaN)
+        diff = diff | ((u1 != u0) & ~(torch.isnan(u1) & torch.isnan(u0))).any(dim=1)
     nb = int(diff.sum())
     nstack += B; ncase += 1; nbad += nb
     if nb:
