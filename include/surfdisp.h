@@ -51,8 +51,9 @@ extern "C" {
                                      * trial velocities; with one batch alone they would leave SIMDs idle) */
 #define SURFDISP_EXACTSCAN     0x80 /* OR into `kind`: every grid point of the scan is evaluated.  Rayleigh: that is the default
                                      * anyway (the flag wins over SURFDISP_FASTSCAN).  Love: the default skips grid points
-                                     * between two coarse points that a counting theorem proves free of roots (same brackets
-                                     * and results, bit for bit); this flag walks them all (what the A/B tests compare with). */
+                                     * between two coarse points that a counting theorem (exact arithmetic) shows free of roots,
+                                     * behind fp32 guards whose margins are soaked, not proved: same brackets and results, bit for
+                                     * bit, on every random stack tried (scripts/soak_cert.py); this flag walks them all. */
 #define SURFDISP_FASTSCAN      0x100 /* OR into `kind`: OPT-IN heuristic scan.  By default the secular function is
                                      * evaluated at EVERY 0.01 km/s grid point from 0.9 c(k-1) up to the first sign
                                      * change, as the reference does (calcul.f:143-166).  With this flag teams of

@@ -965,7 +965,8 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     // judged free of sign changes (see below), otherwise its fine points are scanned as usual
     constexpr int FSTRIDE = (FAST && (KIND == 1 || SD_RCERT) && G <= 4) ? SD_CERT_STRIDE : 4;
     constexpr bool fastok = FAST && (G >= 2) && (G <= 8);
-    // CERT (Love): the coarse scan's certificate is a THEOREM instead of the heuristics below.  At fixed frequency the angle of
+    // CERT (Love): the coarse scan's certificate is a theorem IN EXACT ARITHMETIC (instead of the heuristics below) behind fp32
+    // guards - the "unsafe count" tests - whose margins are soaked, not proved.  At fixed frequency the angle of
     // the pair (displacement, stress) at the surface, followed continuously up from the half space, falls monotonically as
     // the trial velocity rises (Sturm / Pruefer), and a mode sits wherever it passes a multiple of pi: the number of modes
     // between two trial velocities is the difference of their crossing counts (delta_love<true>; checked against brute-force
