@@ -313,7 +313,7 @@ def workload_forward(rt, args):
     steps(args.steps, NFLIGHT)                             # THE timed region of `value`
     rt.barrier()
     elapsed = time.perf_counter() - t0
-    # beside the headline: the same workload with the opt-in heuristic scan (SURFDISP_FASTSCAN, include/surfdisp.h)
+    # beside the headline: the same workload with the opt-in count-guided scan (SURFDISP_FASTSCAN, include/surfdisp.h)
     steps(args.warmup, NFLIGHT, fast_scan=True)
     rt.barrier()
     t0 = time.perf_counter()

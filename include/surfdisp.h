@@ -54,17 +54,19 @@ extern "C" {
                                      * between two coarse points that a counting theorem (exact arithmetic) shows free of roots,
                                      * behind fp32 guards whose margins are soaked, not proved: same brackets and results, bit for
                                      * bit, on every random stack tried (scripts/soak_cert.py); this flag walks them all. */
-#define SURFDISP_FASTSCAN      0x100 /* OR into `kind`: OPT-IN heuristic scan.  By default the secular function is
-                                     * evaluated at EVERY 0.01 km/s grid point from 0.9 c(k-1) up to the first sign
-                                     * change, as the reference does (calcul.f:143-166).  With this flag teams of
-                                     * 2..8 lanes step over four grid points at a time where a set of smoothness and
-                                     * mode-spacing tests (DESIGN.md "fast scan") finds no room for a pair of roots,
-                                     * and rescan point by point elsewhere: ~45 % fewer evaluations.  It is a measured
-                                     * argument, not a proof: differential soaks found 146 of 4.7e9 phase velocities
-                                     * (layers of 0.1-0.3 km/s at periods of 20-300 s) where the two scans return
-                                     * different roots or a different zero pattern.  Callers who need the reference's
-                                     * root selection on every input leave it off.  Also switched on for every call of
-                                     * the process by the environment variable SURFDISP_FASTSCAN=1 (read once). */
+#define SURFDISP_FASTSCAN      0x100 /* OR into `kind`: OPT-IN count-guided scan (Rayleigh; Love's certified scan is on by default).
+                                     * By default the secular function is evaluated at EVERY 0.01 km/s grid point from
+                                     * 0.9 c(k-1) up to the first sign change, as the reference does (calcul.f:143-166).
+                                     * With this flag teams of 2..8 lanes evaluate every 4th / 6th grid point together with the
+                                     * number of mode branches below the trial (a Wittrick-Williams count carried by the
+                                     * recursion: exact in exact arithmetic) and skip the points between two trials with EQUAL
+                                     * counts; any other interval is rescanned point by point: ~45 % fewer evaluations.  Equal
+                                     * counts exclude a root between the two trials unless a branch with a zero-group-velocity
+                                     * point is crossed twice there (Rayleigh branches of soft sediments with Vp/Vs near 3 can
+                                     * have one; Love branches cannot): bit-identical to the default scan on all but one of
+                                     * 5e8 random stacks.  Callers who need the reference's root
+                                     * selection on every input leave it off.  Also switched on for every call of the process
+                                     * by the environment variable SURFDISP_FASTSCAN=1 (read once). */
 #define SURFDISP_STRICT        0x200 /* OR into `kind`: verification mode.  EVERY stack is solved by the kernel that restates
                                      * DLTAR4 / DLTAR1 / NEVILL statement by statement (the one the default mode keeps for
                                      * stacks whose secular function leaves the fp32 range): the reference's own matrix-entry

@@ -384,26 +384,32 @@ __device__ __forceinline__ RState ray_start(const RTrial &t, const int start, co
 }
 // FIRST: only the TOP layer may be liquid in the production kernel (a stack with a liquid layer further down is handed
 // to the exact fallback kernel by the prep kernel's statistics), so the test is made once per evaluation
-// CERT (r04, the certified coarse scan for Rayleigh): the state's first component b1 is det U of the two solutions that satisfy
-// the free-surface condition (start: U = I, tractions 0).  The number of modes with phase velocity below the trial c is
-//      N(c) = #{sign changes of b1 on the way down} + #{positive eigenvalues of Z_h - Z_s at the top of the half space}
+// CERT (r04, the COUNT-GUIDED coarse scan for Rayleigh - the opt-in SURFDISP_FASTSCAN; the default scan walks every grid point):
+// the state's first component b1 is det U_s of the two solutions that satisfy the free-surface condition (start: U = I, tractions
+// 0).  At a trial (k, omega) the number of mode branches below it is
+//      N = #{zeros of det U_s(z) over the stack} + #{positive eigenvalues of Z_h - Z_s at the top of the half space}
 // (Morse index of the Neumann problem + the half space's boundary index; Z = T U^-1 with the tractions ordered (tr, tz), which
-// makes the motion-stress system Hamiltonian and Z symmetric; scripts/analysis/rayleigh_count*.py: holds with a constant offset
-// over the whole range of c on every random stack tried).  NOT A CERTIFICATE, and not used by the default build (SD_RCERT): the
-// sign changes AT THE INTERFACES miss zeros of b1 that come in pairs inside one layer - a thick evanescent layer (27 km of rock at
-// 10 s), but also a thin one whose S velocity the trial is passing (a 2.7 km layer of 0.71 km/s at c = 0.70: two zeros, vertical
-// phase 1.8 rad) -, and there is no closed per-layer count like Love's rotation angle: with every guard below in place 25 of
-// 1.3e8 soak stacks still came back on another root (profiles/r04a/rayleigh_count.txt).  Measured in float64 (2 003 trials on random stacks with
-// soft tops and layers of 2 - 40 km): no zero is missed while k d (|r_alpha| + |r_beta|) - vertical phase or decay exponent alike -
-// stays below 5 in every layer, 13 % of the trials miss some beyond.  kc counts the sign changes, kunc flags a trial whose
-// count is not safe: a layer beyond SD_RCERT_PHASE (3.0: the margin is the soak's to confirm - an empirical guard, NOT a theorem,
-// unlike Love's), or a new b1 that is the remainder of a cancellation (its sign within rounding).
+// makes the motion-stress system Hamiltonian and Z symmetric).  The zeros are counted LAYER BY LAYER, inside each layer, by
+// Wittrick and Williams' rule (below) - exact in exact arithmetic while every oscillatory layer's S phase stays below pi
+// (scripts/analysis/rayleigh_count_ww*.py: equal to the brute-force count on every such trial of 50 random stacks).  The first
+// attempt (SD_RCERT == 2) looked at the sign of b1 at the interfaces only and missed pairs of zeros inside one layer
+// (profiles/r04a/rayleigh_count.txt: 25 of 1.3e8 soak stacks on another root).
+// What the count is NOT: a proof that an interval between two trials with equal counts holds no root.  Along the scan's line
+// omega = const the count rises where the line crosses a branch whose group velocity is positive and FALLS where it is negative:
+// a branch with a zero-group-velocity point (soft sediments with Vp/Vs near 3 over rock) can be crossed twice between two coarse
+// points, +1 then -1.  Love branches cannot (their group velocity is an energy ratio of one sign; the Love certificate is a
+// theorem); Rayleigh ones can, and one soak stack in 5e8 did (profiles/r04b/rayleigh_count_ww.txt).  Hence opt-in.
+// kc accumulates the count, kunc flags a trial whose count is not safe (a sign within rounding, an S phase beyond the bound, a
+// liquid layer).
 #ifndef SD_RCERT_PHASE
 #define SD_RCERT_PHASE 3.0f
 #endif
+#ifndef SD_RCERT_SPHASE
+#define SD_RCERT_SPHASE 3.0f    // S phase (rad) of an oscillatory layer up to which its in-layer count is taken (the theorem's bound: pi)
+#endif
 #ifndef SD_RCERT
-#define SD_RCERT 0              // 1: the Rayleigh count drives the coarse scan (experimental builds; 46.6 M solves/s on the bench batch,
-#endif                          // 25 of 1.3e8 soak stacks on another root: profiles/r04a/rayleigh_count.txt)
+#define SD_RCERT 1              // 1: the Rayleigh FAST instantiations (opt-in, SURFDISP_FASTSCAN) are the count-guided scan; 0: the r01
+#endif                          // heuristic scan; 2: the first attempt (interface-only count; profiles/r04a/rayleigh_count.txt)
 template <bool FIRST, bool CERT = false>
 __device__ __forceinline__ void ray_step(RState &s, const RTrial &t, const RLyr &y, const int start, float &phi, int *kc = nullptr,
                                          bool *kunc = nullptr)
@@ -480,9 +486,44 @@ __device__ __forceinline__ void ray_step(RState &s, const RTrial &t, const RLyr 
     const float E2 = fmaf(sinpr, t2, fmaf(Cy, h2, D * u1));
     const float n1 = (b1 - E1) - E2;
     if (CERT) {
+#if SD_RCERT == 2
+        // (first attempt, kept for the record: sign changes of b1 at the interfaces only - misses pairs of zeros inside a layer)
         *kc += ((n1 < 0.0f) != (b1 < 0.0f)) ? 1 : 0;
         *kunc = *kunc || !(fabsf(pm) + fabsf(qm) < SD_RCERT_PHASE) ||
                 !(fabsf(n1) > 1.0e-4f * (fabsf(b1) + fabsf(E1) + fabsf(E2)));
+#else
+        // Zeros of det U_s INSIDE this layer (Wittrick-Williams).  With the surface pair's impedance Z_t at the layer's top and the
+        // layer's propagator in blocks, det U_s at depth z below the top vanishes where M(z) = Z_t - K11(z) is singular, K11 = the
+        // impedance of the slab clamped at z seen from its top; M(0+) is positive definite and - as long as no clamped-clamped
+        // mode of the slab lies below the frequency, which Korn's inequality guarantees while the S phase k d r_beta < pi (and
+        // always where S is evanescent) - its eigenvalues only move down: the zeros inside the layer = the negative eigenvalues
+        // of M(d), 0, 1 or 2.  n1 is linear in the state, n1 = c1 b1 + c2 h2 + c3 h3 + c4 h4 + c5 h5, and for a state that is the
+        // minors of [I; Z] (b1 = 1, h2 = -z22, h3 = -z12, h4 = z11, h5 = det Z) that is c5 det(Z - K11): K11's entries are ratios
+        // of the coefficients, and
+        //      det M = n1 / (b1 c5),      M11 = (h4 c5 - c2 b1) / (b1 c5),
+        //      c5 = rsinp rsinq + sinpr sinqr + 2 (1 - cosp cosq),   c2 = -(rsinp cosq + cosp sinqr)
+        // (scripts/analysis/rayleigh_count_ww*.py: per layer and in total equal to the finely stepped / brute-force counts on
+        // every trial with all S phases below pi).  Unsafe: an oscillatory layer beyond SD_RCERT_SPHASE, or any of the three
+        // signs within rounding (n1, c5, and - where it decides - M11's numerator against their own terms).
+        const float p1 = rsinp * rsinq, p2 = sinpr * sinqr;
+        const float c5 = p1 + p2 + (D + D);
+        const float c2 = -fmaf(rsinp, cosq, Cy);
+        const float bc = b1 * c5;
+        const float m11a = h4 * c5, m11b = c2 * b1;
+        const float m11n = m11a - m11b;
+        const bool dneg = (n1 < 0.0f) != (bc < 0.0f);
+        const bool mneg = (m11n < 0.0f) != (bc < 0.0f);
+        *kc += dneg ? 1 : (mneg ? 2 : 0);
+        *kunc = *kunc || (!(argb > 0.0f) && !(fabsf(qm) < SD_RCERT_SPHASE)) ||
+                !(fabsf(n1) > 1.0e-4f * (fabsf(b1) + fabsf(E1) + fabsf(E2))) ||
+                !(fabsf(c5) > 1.0e-4f * (fabsf(p1) + fabsf(p2) + 2.0f * fabsf(D))) ||
+                (!dneg && !(fabsf(m11n) > 1.0e-4f * (fabsf(m11a) + fabsf(m11b)))) || !(fabsf(bc) > 0.0f);
+#ifdef SD_DEBUG_COUNT
+        if (csq > SD_DEBUG_COUNT * SD_DEBUG_COUNT && csq < (SD_DEBUG_COUNT + 0.07f) * (SD_DEBUG_COUNT + 0.07f))
+            printf("   layer c %.6f: b1 % .5e n1 % .5e c5 % .5e (p1 % .3e p2 % .3e 2D % .3e) m11n % .5e (%.3e, %.3e) det<0 %d m11<0 %d count %d qm %.3f pm %.3f unsafe %d\n",
+                   sqrtf(csq), b1, n1, c5, p1, p2, D + D, m11n, m11a, m11b, (int)dneg, (int)mneg, *kc, qm, pm, (int)*kunc);
+#endif
+#endif
     }
     const float n3 = fmaf(g, E1, fmaf(g1, E2, h3));
     const float n5 = fmaf(g2, E1, fmaf(g12, E2, h5));
@@ -532,6 +573,11 @@ __device__ __forceinline__ float ray_close(const RState &s, const RTrial &t, con
         const float S11 = -zf * rap - sf * s.h4, S12 = zf * zo + sf * s.h3, S22 = -zf * rbp + sf * s.h2;
         const float dq = S11 * S22 - S12 * S12, tp = S11 + S22;
         *kc += (dq < 0.0f) ? 1 : ((tp > 0.0f) ? 2 : 0);
+#ifdef SD_DEBUG_COUNT
+        if (csq > SD_DEBUG_COUNT * SD_DEBUG_COUNT && csq < (SD_DEBUG_COUNT + 0.07f) * (SD_DEBUG_COUNT + 0.07f))
+            printf("   half space c %.6f: S11 % .5e (%.3e - %.3e) S12 % .5e S22 % .5e (%.3e + %.3e) det % .5e trace % .5e count %d\n",
+                   sqrtf(csq), S11, -zf * rap, sf * s.h4, S12, S22, -zf * rbp, sf * s.h2, dq, tp, *kc);
+#endif
         // unsafe: the half space not evanescent in P and S, a determinant or - where it matters - a trace within rounding, not finite
         *kunc = *kunc || !(arga > 0.0f) || !(argb > 0.0f) || !(fabsf(dq) > 1.0e-4f * (fabsf(S11 * S22) + S12 * S12)) ||
                 (dq > 0.0f && !(fabsf(tp) > 1.0e-4f * (fabsf(S11) + fabsf(S22)))) || !fin(dq) || !fin(s.b1) || s.b1 == 0.0f;
@@ -978,8 +1024,8 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
     // lanes (deep stacks) one plain pass already covers 16 grid points and the coarse pass's dearer evaluations ate the
     // gain (16 384 x L64: 1.12 -> 1.21 ms), so they keep the plain scan.  Checked against the point-by-point scan bit for
     // bit on 5.7e8 random stacks (scripts/soak_cert.py).
-    // (Rayleigh: -DSD_RCERT=1 builds only - the count of ray_step / ray_close is NOT a certificate: see there and
-    // profiles/r04a/rayleigh_count.txt; by default Rayleigh's FAST instantiations are the opt-in heuristic scan of r01.)
+    // (Rayleigh: the FAST instantiations are opt-in - SURFDISP_FASTSCAN - and run the same coarse scan on the count of ray_step /
+    // ray_close, which is exact but not monotone along the scan line where a branch has a zero-group-velocity point: see there.)
     constexpr bool CERT = fastok && (KIND == 1 || SD_RCERT) && !EXACT;
     int p0Kp = 0x40000000;             // Sturm count at p0 (CERT), packed: count + 4096, bit 30 = unsafe
     // ... and only on stacks where two modes cannot sit within one coarse interval: velocities that never
@@ -1327,7 +1373,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs &A)
         const bool cross = has_prev && (negnan(val) != negnan(pd));
 #ifdef SD_DEBUG_TRIALS   // (developer build: every evaluated trial of a one-stack call)
         if (A.B == 1 && eval && k == SD_DEBUG_TRIALS && cj > SD_DEBUG_CMIN)
-            printf("k %d pass %d st %d lane %d c %.7f val % .6e mm %d | p0c %.7f p0d % .4e cb %.7f db % .4e\n", k, passes, st, j, cj, val, mmj, p0c, p0d, cb, db);
+            printf("k %d pass %d st %d lane %d c %.7f val % .6e mm %d count %d unsafe %d coarse %d | p0c %.7f p0d % .4e cb %.7f db % .4e\n", k, passes, st, j, cj, val, mmj, kcj, (int)kuncj, (int)coarse, p0c, p0d, cb, db);
 #endif
         bool guard = false;
         if (st == ST_SCAN && has_prev && !cross)               // calcul.f:165-166
