@@ -484,6 +484,29 @@ def test_independent_mode_failure_cascade_and_water(hip, ref_cases):
     assert np.isfinite(c).all() and c.shape == d["c"].shape
 
 
+def test_default_scan_on_the_zero_group_velocity_stack(hip):
+    """tests/golden/ref_zgv_stack.npz: a soft-sediment stack (Vs 0.28 ... 1.3 km/s, Vp/Vs 2.9, over 4.6 km/s) whose secular function
+    dips below zero between c = 0.946 and 0.981 at T = 23.78 s - two roots 0.035 km/s apart on a branch with a zero-group-velocity
+    point.  The DEFAULT scan walks every grid point and returns the reference's root for every team size; the opt-in count-guided
+    scan (SURFDISP_FASTSCAN) steps over the pair - the count is the same on both sides - and is allowed to: the fixture records what
+    it returned, and the test only checks that it returns either of the two."""
+    from pysurfinv_amd import _lib
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_zgv_stack.npz"))
+    m = d["model"][None]; per = d["periods"]
+    for team in (0, 1, 2, 4, 8, 16):
+        assert _lib.lib().surfdisp_set_team(team) == 0
+        try:
+            c, u, st = hip.forward_batch(m, per, 2)
+            cf, uf, sf = hip.forward_batch(m, per, 2, fast_scan=True)
+        finally:
+            _lib.lib().surfdisp_set_team(0)
+        assert np.array_equal(c[0] > 0, d["c"] > 0)
+        ok = d["c"] > 0
+        assert np.abs(c[0][ok] / d["c"][ok] - 1).max() < 2e-5
+        near = lambda a, b: np.abs(a[ok] / np.where(b[ok] > 0, b[ok], 1) - 1) < 2e-5
+        assert (near(cf[0], d["c"]) | near(cf[0], d["c_count_guided"])).all()
+
+
 def test_love_overflow_stacks_go_through_the_exact_kernel(hip):
     """DLTAR1 carries (ut, tt) through the layers without normalisation (surfa.f:143-179): three 300 km layers at 2-4 s put
     e^(several hundred) into the pair, the reference scans NaNs and returns the edge of the overflowed region.  The production

@@ -200,3 +200,13 @@ def test_oracle_bit_exact_on_the_soak_offender_fixture():
         n, P = int(f["nlay"][q]), int(f["P"][q])
         c, u, st = cport.forward_batch(np.ascontiguousarray(f["model"][q][None, :, :n]), f["per"][q][:P], int(f["kind"][q]))
         assert np.array_equal(c[0], f["c"][q][:P]), q
+
+
+def test_oracle_on_the_zero_group_velocity_stack():
+    """tests/golden/ref_zgv_stack.npz (reference outputs of the one stack on which the opt-in count-guided scan left the point-by-point
+    scan): the oracle returns the reference's phase and group velocities bit for bit."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_zgv_stack.npz"))
+    c, u, s = cport.forward_batch(d["model"][None], d["periods"], 2)
+    assert np.array_equal(c[0], d["c"])
+    assert np.array_equal(np.nan_to_num(u[0], nan=-1.0), np.nan_to_num(d["u"], nan=-1.0))
