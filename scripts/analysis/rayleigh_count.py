@@ -16,7 +16,7 @@ import sys
 import numpy as np
 from scipy.linalg import expm
 
-rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 0)
 
 
 def layer_matrix(k, om, a, b, rho):
