@@ -63,8 +63,8 @@ extern "C" {
                                      * counts; any other interval is rescanned point by point: ~45 % fewer evaluations.  Equal
                                      * counts exclude a root between the two trials unless a branch with a zero-group-velocity
                                      * point is crossed twice there (Rayleigh branches of soft sediments with Vp/Vs near 3 can
-                                     * have one; Love branches cannot): bit-identical to the default scan on all but one of
-                                     * 5e8 random stacks.  Callers who need the reference's root
+                                     * have one; Love branches cannot): bit-identical to the default scan on all but two of
+                                     * 1.2e9 random stacks.  Callers who need the reference's root
                                      * selection on every input leave it off.  Also switched on for every call of the process
                                      * by the environment variable SURFDISP_FASTSCAN=1 (read once). */
 #define SURFDISP_STRICT        0x200 /* OR into `kind`: verification mode.  EVERY stack is solved by the kernel that restates

@@ -398,7 +398,7 @@ __device__ __forceinline__ RState ray_start(const RTrial &t, const int start, co
 // omega = const the count rises where the line crosses a branch whose group velocity is positive and FALLS where it is negative:
 // a branch with a zero-group-velocity point (soft sediments with Vp/Vs near 3 over rock) can be crossed twice between two coarse
 // points, +1 then -1.  Love branches cannot (their group velocity is an energy ratio of one sign; the Love certificate is a
-// theorem); Rayleigh ones can, and one soak stack in 5e8 did (profiles/r04b/rayleigh_count_ww.txt).  Hence opt-in.
+// theorem); Rayleigh ones can, and two soak stacks in 1.2e9 did (profiles/r04b/rayleigh_count_ww.txt).  Hence opt-in.
 // kc accumulates the count, kunc flags a trial whose count is not safe (a sign within rounding, an S phase beyond the bound, a
 // liquid layer).
 #ifndef SD_RCERT_PHASE
