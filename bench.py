@@ -379,6 +379,9 @@ def workload_forward(rt, args):
         "stacks_through_exact_fallback": n_fb,
         "value_one_batch_in_flight": world * B_PER_GPU * args.steps / elapsed_one,
         "value_fast_scan": world * B_PER_GPU * args.steps / elapsed_fast,
+        "fast_scan": "opt-in SURFDISP_FASTSCAN, NOT the headline: coarse scan guided by an exact count of the mode branches below each "
+                     "trial (Wittrick-Williams, carried by the recursion); equal counts do not exclude a branch crossed twice at a "
+                     "zero-group-velocity point - 2 of 1.2e9 soak stacks differed from the point-by-point scan (DESIGN.md section 10)",
         "kernel_ms": {"prep": kms[0], "phase": kms[1], "group_and_finish": kms[2],
                       "how": "HIP events recorded on the launch stream around each kernel of the K timed "
                              "one-batch-in-flight steps, read after the closing synchronisation; phase = root search + "
