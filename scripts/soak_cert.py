@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""GPU box: the certified coarse scan (default; Love since r03, Rayleigh since r04: SOAK_KIND=2) against the point-by-point scan
+"""GPU box: the coarse scans - Love's certified one (default since r03) and, with SOAK_KIND=2 and SURFDISP_FASTSCAN=1 in the environment,
+Rayleigh's opt-in count-guided one (r04) - against the point-by-point scan
 (SURFDISP_EXACTSCAN) on random stacks - the two must agree BIT FOR BIT (same brackets, same refinement); any differing stack is a
 failed certificate.  SOAK_SECONDS, SOAK_SEED, SOAK_KIND (1 Love, 2 Rayleigh), SOAK_CU=1: c+U calls instead of phase-only ones, SOAK_DEEP=1: stacks of up to 96 layers (default: below 48)."""
 import os, sys, time
@@ -59,5 +60,5 @@ while time.time() < T_END:
 _lib.lib().surfdisp_set_team(0)
 if dump:
     np.savez_compressed(os.environ['SOAK_DUMP'], **{k: np.array([d[k] for d in dump]) for k in dump[0]})
-print(f"certified {'Love' if KIND == 1 else 'Rayleigh'} scan vs point-by-point scan: {ncase} cases, {nstack} stacks, {nbad} differing stacks")
+print(f"{'certified Love' if KIND == 1 else 'count-guided Rayleigh (SURFDISP_FASTSCAN)'} scan vs point-by-point scan: {ncase} cases, {nstack} stacks, {nbad} differing stacks")
 sys.exit(1 if nbad else 0)
